@@ -1,0 +1,149 @@
+/*
+ * ttx.h — C ABI of libttx_hip.so: MI355X-native (gfx950) encoder–decoder forward and speculative
+ * decoding for the Molecular Transformer hot path of Academich/translation-transformer.
+ *
+ * The reference has no FFI: its hot path is Python calling stock torch ops.  Each entry point below
+ * names the reference function it replaces (paths relative to the reference root).  Conventions:
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller (a torch tensor's data_ptr());
+ *     the library borrows it for the duration of the call and never frees it;
+ *   - token tensors are int64 row-major exactly as the reference's LongTensors; floats are fp32;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued on it; calls that return host-side results synchronise that stream before returning;
+ *   - every function returns 0 on success or a negative ttx_status; ttx_last_error() gives the text
+ *     (thread-local).  Nothing throws across the boundary;
+ *   - one host thread drives one ttx_session at a time (the Lightning predict loop is sequential:
+ *     src/model/lightning_model.py:209-212); distinct sessions on distinct streams may run concurrently.
+ */
+#ifndef TTX_H
+#define TTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTX_ABI_VERSION 1
+
+typedef enum ttx_status {
+  TTX_OK = 0,
+  TTX_ERR_INVALID = -1,      /* bad argument / shape                                             */
+  TTX_ERR_HIP = -2,          /* a HIP runtime call failed                                        */
+  TTX_ERR_NO_DEVICE = -3,    /* no gfx950 device visible: the library has NO CPU fallback         */
+  TTX_ERR_REFERENCE = -4,    /* input on which the reference itself raises (see ttx_last_error)  */
+  TTX_ERR_NOMEM = -5
+} ttx_status;
+
+/* Model hyper-parameters: the init_args of VanillaTransformer (src/model/modules.py:11-38). */
+typedef struct ttx_config {
+  int32_t vocab_size;           /* tgt (= src when shared) vocabulary                          */
+  int32_t src_vocab_size;
+  int32_t embedding_dim;        /* d: multiple of 64, <= 1024                                  */
+  int32_t num_heads;            /* d / num_heads must be 32                                    */
+  int32_t feedforward_dim;      /* multiple of 64                                              */
+  int32_t num_encoder_layers;
+  int32_t num_decoder_layers;
+  int32_t pad_token;            /* src == tgt pad id (0 in the reference: tokenizer_base.py:27) */
+  int32_t max_positions;        /* rows of the sinusoid table minus one (embeddings.py:31: 5000) */
+  float   layer_norm_eps;       /* modules.py:52: 1e-5                                         */
+} ttx_config;
+
+typedef struct ttx_model ttx_model;      /* weights resident in HBM                          */
+typedef struct ttx_session ttx_session;  /* workspaces, KV caches, captured graphs, one stream at a time */
+
+/* One named fp32 host tensor of the reference state dict ("model." prefix stripped). */
+typedef struct ttx_tensor {
+  const char*  name;
+  const float* data;      /* HOST pointer, row-major */
+  int64_t      numel;
+} ttx_tensor;
+
+/* Library / device ----------------------------------------------------------------------------- */
+int         ttx_abi_version(void);
+const char* ttx_last_error(void);
+/* Number of visible gfx950 devices (0 when there is none; never raises). */
+int         ttx_device_count(void);
+
+/* Weights in: replaces VanillaTransformer.__init__ + load_state_dict (modules.py:11-84; checkpoint key
+ * layout of lightning_model.py / tests/test_batching.py:48-49).  Tensors are looked up by name; a
+ * missing or mis-sized tensor is TTX_ERR_INVALID.  The sinusoid table (embeddings.py:38-45, not in the
+ * state dict) is rebuilt on the host with the same fp32 formula. */
+int  ttx_model_create(const ttx_config* cfg, const ttx_tensor* tensors, int n_tensors, int device,
+                      ttx_model** out);
+void ttx_model_destroy(ttx_model* m);
+/* Packed weight blob (all weights, one contiguous device allocation) for the RCCL broadcast of
+ * rank 0 creates the model from host tensors, every other rank creates it with
+ * ttx_model_create_empty and receives the blob with one ncclBroadcast on [ptr, ptr+bytes). */
+int  ttx_model_create_empty(const ttx_config* cfg, int device, ttx_model** out);
+int  ttx_model_blob(ttx_model* m, void** d_ptr, int64_t* bytes);
+
+int  ttx_session_create(ttx_model* m, ttx_session** out);
+void ttx_session_destroy(ttx_session* s);
+
+/* Model protocol ---------------------------------------------------------- */
+
+/* VanillaTransformer.encode_src (modules.py:110-116).  d_src: int64 [B,Ls]; PAD keys masked
+ * (src == pad_token); d_memory: fp32 [B,Ls,d] out, rows at PAD positions are written as zeros. */
+int ttx_encode_src(ttx_session* s, const int64_t* d_src, int B, int Ls, float* d_memory, void* stream);
+
+/* VanillaTransformer.decode_tgt (modules.py:118-138): full-prefix decoder forward + classifier.
+ * d_tgt int64 [R,Lt]; d_memory fp32 [Rm,Ls,d]; d_mem_pad uint8 [Rm,Ls] (1 = PAD key);
+ * d_mem_row int32 [R] maps decoder row -> memory row (NULL: identity, Rm == R, i.e. the reference's
+ * inflated memory); d_logits fp32 [R,Lt,V] out. */
+int ttx_decode_tgt(ttx_session* s, const int64_t* d_tgt, int R, int Lt, const float* d_memory,
+                   const uint8_t* d_mem_pad, const int32_t* d_mem_row, int Rm, int Ls, float* d_logits,
+                   void* stream);
+
+/* VanillaTransformer.forward (modules.py:86-108; step 0 of standard beam search). d_logits [B,Lt,V]. */
+int ttx_forward(ttx_session* s, const int64_t* d_src, int B, int Ls, const int64_t* d_tgt, int Lt,
+                float* d_logits, void* stream);
+
+/* Draft maker: make_drafts (src/utils/drafting.py:5-67) on the device.  d_src int64 [B,L];
+ * d_drafts int64 [B,n_drafts,D] out with D = clamp(draft_len, min_draft_len, max_draft_len). */
+int ttx_make_drafts(ttx_session* s, const int64_t* d_src, int B, int L, int draft_len, int n_drafts,
+                    int min_draft_len, int max_draft_len, int eos_token, int pad_token, int replace_token,
+                    int64_t* d_drafts, void* stream);
+
+/* Generators -------------------------------------------------------------- */
+
+typedef struct ttx_gen_params {
+  int32_t max_len;
+  int32_t draft_len;       /* greedy-speculative: D (clamped to [1,max_len] as speculative_decoding.py:64-73) */
+  int32_t n_drafts;        /* N */
+  int32_t pad_token, bos_token, eos_token, replace_token;
+  int32_t want_logits;     /* debug/parity: also keep pre-argmax logits of the verify positions */
+} ttx_gen_params;
+
+typedef struct ttx_gen_stats {
+  int64_t model_calls;         /* decoder invocations == verify steps (generator.model_calls_num)      */
+  int64_t accepted_tokens;     /* draft tokens accepted over all rows and steps                        */
+  int64_t produced_tokens;     /* tokens written (accepted + one bonus token per row per step)         */
+  int64_t verified_positions;  /* sum over steps of Bc*N*(D+1): rows of the step's GEMMs               */
+  int64_t kv_prefix_positions; /* sum over steps and running rows of the cached prefix length          */
+  int64_t src_positions;       /* sum over steps of Bc*Ls (cross-attention keys read)                  */
+  double  encode_ms, decode_ms;/* device time (HIP events on `stream`) of the two phases               */
+} ttx_gen_stats;
+
+/* TranslationInferenceGreedySpeculative.generate (src/decoding/speculative_decoding.py:39-174) with a
+ * KV cache: encoder once, cross-attention K/V projected once per source, D+1 new positions per draft per
+ * step.  d_src int64 [B,Ls]; d_out int64 [B,1,max_len] (PAD-filled; rows that never reach EOS stay
+ * all-PAD exactly as the reference leaves them).  Returns TTX_ERR_REFERENCE where the reference raises
+ * (a row finishing at a width beyond max_len, :158). */
+int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_src, int B, int Ls,
+                                    const ttx_gen_params* p, int64_t* d_out, ttx_gen_stats* stats,
+                                    void* stream);
+
+/* TranslationInferenceGreedy.generate (src/decoding/standard_decoding.py:30-55) with a KV cache.
+ * d_out int64 [B,1,max_len]. */
+int ttx_greedy_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p,
+                        int64_t* d_out, ttx_gen_stats* stats, void* stream);
+
+/* Timing of the dominant kernel for bench.py's roofline: summed HIP-event time (events recorded on the
+ * launch stream around every k_gemm_tn launch) and launch count of the most recent generate call on this
+ * session.  Only collected when the session was created with TTX_PROFILE_GEMM=1 in the environment. */
+int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTX_H */

@@ -1,0 +1,6 @@
+"""translation-transformer_amd: MI355X-native speculative-decoding inference path of
+Academich/translation-transformer.  Import as ``translation_transformer_amd`` through the
+shim at the repository root (the directory name carries a hyphen)."""
+from ._native import build, lib, TtxError, ReferenceError_  # noqa: F401
+from .model import NativeTransformer, reference_pe_table  # noqa: F401
+from .decoding import TranslationInferenceGreedySpeculative  # noqa: F401

@@ -1,0 +1,809 @@
+// Host side of libttx_hip.so: the C ABI of include/ttx.h over the kernels of ttx_kernels.hip.h.
+// No CPU fallback exists anywhere in this file: without a gfx950 device every entry point fails.
+#include "ttx.h"
+#include "ttx_kernels.hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ttx;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return fail(TTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+                                   std::to_string(__LINE__) + ")");                                    \
+  } while (0)
+
+#define TTX_TRY(expr)        \
+  do {                       \
+    int _r = (expr);         \
+    if (_r != TTX_OK) return _r; \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------
+struct LayerW {
+  // offsets (in floats) into the blob
+  size_t sa_in_w, sa_in_b, sa_out_w, sa_out_b;
+  size_t ca_in_w, ca_in_b, ca_out_w, ca_out_b;  // decoder only
+  size_t l1_w, l1_b, l2_w, l2_b;
+  size_t n1_w, n1_b, n2_w, n2_b, n3_w, n3_b;
+};
+
+struct ttx_model {
+  ttx_config cfg;
+  int device;
+  float* blob = nullptr;
+  size_t blob_floats = 0;
+  std::map<std::string, std::pair<size_t, size_t>> index;  // name -> (offset, numel)
+  std::vector<LayerW> enc, dec;
+  size_t src_emb, tgt_emb, enc_norm_w, enc_norm_b, dec_norm_w, dec_norm_b, cls_w, cls_b, pe;
+  size_t cross_kv_w, cross_kv_b;  // packed [Ld*2d, d] / [Ld*2d]: cross-attention K,V rows of every decoder layer
+  const float* p(size_t off) const { return blob + off; }
+};
+
+static void layout_add(ttx_model* m, const std::string& name, size_t numel, size_t* off_out) {
+  size_t off = (m->blob_floats + 63) & ~(size_t)63;
+  m->index[name] = {off, numel};
+  m->blob_floats = off + numel;
+  if (off_out) *off_out = off;
+}
+
+static int build_layout(ttx_model* m) {
+  const ttx_config& c = m->cfg;
+  const size_t d = c.embedding_dim, F = c.feedforward_dim, V = c.vocab_size, Vs = c.src_vocab_size;
+  if (c.embedding_dim <= 0 || c.embedding_dim % 64 || c.embedding_dim > 1024)
+    return fail(TTX_ERR_INVALID, "embedding_dim must be a multiple of 64 in [64,1024]");
+  if (c.num_heads <= 0 || c.embedding_dim / c.num_heads != ATT_DH || c.embedding_dim % c.num_heads)
+    return fail(TTX_ERR_INVALID, "embedding_dim / num_heads must be 32");
+  const int vpl = c.embedding_dim / 64;
+  if (vpl != 1 && vpl != 2 && vpl != 4 && vpl != 8 && vpl != 16)
+    return fail(TTX_ERR_INVALID, "embedding_dim must be 64, 128, 256, 512 or 1024");
+  if (c.feedforward_dim <= 0 || c.feedforward_dim % 64) return fail(TTX_ERR_INVALID, "feedforward_dim must be a multiple of 64");
+  if (c.vocab_size <= 0 || c.src_vocab_size <= 0) return fail(TTX_ERR_INVALID, "vocab sizes must be positive");
+  if (c.num_encoder_layers <= 0 || c.num_decoder_layers <= 0) return fail(TTX_ERR_INVALID, "layer counts must be positive");
+  if (c.max_positions <= 0) return fail(TTX_ERR_INVALID, "max_positions must be positive");
+
+  auto attn = [&](const std::string& p, size_t* iw, size_t* ib, size_t* ow, size_t* ob) {
+    layout_add(m, p + ".in_proj_weight", 3 * d * d, iw);
+    layout_add(m, p + ".in_proj_bias", 3 * d, ib);
+    layout_add(m, p + ".out_proj.weight", d * d, ow);
+    layout_add(m, p + ".out_proj.bias", d, ob);
+  };
+  auto ffn = [&](const std::string& p, LayerW& w) {
+    layout_add(m, p + ".linear1.weight", F * d, &w.l1_w);
+    layout_add(m, p + ".linear1.bias", F, &w.l1_b);
+    layout_add(m, p + ".linear2.weight", d * F, &w.l2_w);
+    layout_add(m, p + ".linear2.bias", d, &w.l2_b);
+  };
+  auto norm = [&](const std::string& p, size_t* w, size_t* b) {
+    layout_add(m, p + ".weight", d, w);
+    layout_add(m, p + ".bias", d, b);
+  };
+  layout_add(m, "src_token_featurizer.embedding.weight", Vs * d, &m->src_emb);
+  layout_add(m, "tgt_token_featurizer.embedding.weight", V * d, &m->tgt_emb);
+  m->enc.resize(c.num_encoder_layers);
+  for (int i = 0; i < c.num_encoder_layers; ++i) {
+    const std::string p = "transformer.encoder.layers." + std::to_string(i);
+    LayerW& w = m->enc[i];
+    attn(p + ".self_attn", &w.sa_in_w, &w.sa_in_b, &w.sa_out_w, &w.sa_out_b);
+    ffn(p, w);
+    norm(p + ".norm1", &w.n1_w, &w.n1_b);
+    norm(p + ".norm2", &w.n2_w, &w.n2_b);
+  }
+  norm("transformer.encoder.norm", &m->enc_norm_w, &m->enc_norm_b);
+  m->dec.resize(c.num_decoder_layers);
+  for (int i = 0; i < c.num_decoder_layers; ++i) {
+    const std::string p = "transformer.decoder.layers." + std::to_string(i);
+    LayerW& w = m->dec[i];
+    attn(p + ".self_attn", &w.sa_in_w, &w.sa_in_b, &w.sa_out_w, &w.sa_out_b);
+    attn(p + ".multihead_attn", &w.ca_in_w, &w.ca_in_b, &w.ca_out_w, &w.ca_out_b);
+    ffn(p, w);
+    norm(p + ".norm1", &w.n1_w, &w.n1_b);
+    norm(p + ".norm2", &w.n2_w, &w.n2_b);
+    norm(p + ".norm3", &w.n3_w, &w.n3_b);
+  }
+  norm("transformer.decoder.norm", &m->dec_norm_w, &m->dec_norm_b);
+  layout_add(m, "next_token_classifier.weight", V * d, &m->cls_w);
+  layout_add(m, "next_token_classifier.bias", V, &m->cls_b);
+  // derived tensors (not in the state dict)
+  layout_add(m, "positional_encoding.pe", ((size_t)c.max_positions + 1) * d, &m->pe);
+  layout_add(m, "derived.cross_kv.weight", (size_t)c.num_decoder_layers * 2 * d * d, &m->cross_kv_w);
+  layout_add(m, "derived.cross_kv.bias", (size_t)c.num_decoder_layers * 2 * d, &m->cross_kv_b);
+  m->blob_floats = (m->blob_floats + 63) & ~(size_t)63;
+  return TTX_OK;
+}
+
+static bool is_gfx950(int device) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+  return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" int ttx_abi_version(void) { return TTX_ABI_VERSION; }
+extern "C" const char* ttx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int ttx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) ok += is_gfx950(i) ? 1 : 0;
+  return ok;
+}
+
+static int model_alloc(const ttx_config* cfg, int device, ttx_model** out) {
+  if (!cfg || !out) return fail(TTX_ERR_INVALID, "null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(TTX_ERR_NO_DEVICE, "no HIP device visible; libttx_hip has no CPU fallback");
+  if (device < 0 || device >= n) return fail(TTX_ERR_INVALID, "device index out of range");
+  if (!is_gfx950(device)) return fail(TTX_ERR_NO_DEVICE, "device is not gfx950 (MI355X); this library is built for gfx950 only");
+  ttx_model* m = new ttx_model();
+  m->cfg = *cfg;
+  m->device = device;
+  int r = build_layout(m);
+  if (r != TTX_OK) { delete m; return r; }
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&m->blob, m->blob_floats * sizeof(float)) != hipSuccess) {
+    delete m;
+    return fail(TTX_ERR_NOMEM, "hipMalloc of the weight blob failed");
+  }
+  *out = m;
+  return TTX_OK;
+}
+
+extern "C" int ttx_model_create_empty(const ttx_config* cfg, int device, ttx_model** out) {
+  return model_alloc(cfg, device, out);
+}
+
+extern "C" int ttx_model_blob(ttx_model* m, void** d_ptr, int64_t* bytes) {
+  if (!m || !d_ptr || !bytes) return fail(TTX_ERR_INVALID, "null argument");
+  *d_ptr = m->blob;
+  *bytes = (int64_t)(m->blob_floats * sizeof(float));
+  return TTX_OK;
+}
+
+extern "C" int ttx_model_create(const ttx_config* cfg, const ttx_tensor* tensors, int n_tensors, int device,
+                                ttx_model** out) {
+  if (!tensors || n_tensors <= 0) return fail(TTX_ERR_INVALID, "no tensors given");
+  ttx_model* m = nullptr;
+  TTX_TRY(model_alloc(cfg, device, &m));
+  std::vector<float> host(m->blob_floats, 0.f);
+  std::map<std::string, const ttx_tensor*> given;
+  for (int i = 0; i < n_tensors; ++i) {
+    if (!tensors[i].name || !tensors[i].data) { ttx_model_destroy(m); return fail(TTX_ERR_INVALID, "tensor with null name/data"); }
+    std::string nm = tensors[i].name;
+    if (nm.rfind("model.", 0) == 0) nm = nm.substr(6);  // Lightning checkpoint prefix
+    given[nm] = &tensors[i];
+  }
+  for (auto& kv : m->index) {
+    const std::string& nm = kv.first;
+    const bool derived = nm.rfind("derived.", 0) == 0;
+    auto it = given.find(nm);
+    if (it == given.end()) {
+      if (derived || nm == "positional_encoding.pe") continue;
+      ttx_model_destroy(m);
+      return fail(TTX_ERR_INVALID, "missing tensor: " + nm);
+    }
+    if ((size_t)it->second->numel != kv.second.second) {
+      ttx_model_destroy(m);
+      return fail(TTX_ERR_INVALID, "tensor " + nm + " has " + std::to_string(it->second->numel) + " elements, expected " +
+                                       std::to_string(kv.second.second));
+    }
+    std::memcpy(host.data() + kv.second.first, it->second->data, kv.second.second * sizeof(float));
+  }
+  const ttx_config& c = m->cfg;
+  const size_t d = c.embedding_dim;
+  if (given.find("positional_encoding.pe") == given.end()) {
+    // embeddings.py:38-45 in fp32: row 0 zeros, row p+1 = sin/cos(p * exp(2i * (-ln 1e4 / d)))
+    float* pe = host.data() + m->pe;
+    const float cst = (float)(-std::log(10000.0) / (double)d);
+    for (int p = 0; p < c.max_positions; ++p)
+      for (size_t i = 0; i < d; i += 2) {
+        const float div = expf((float)i * cst);
+        const float arg = (float)p * div;
+        pe[(size_t)(p + 1) * d + i] = sinf(arg);
+        pe[(size_t)(p + 1) * d + i + 1] = cosf(arg);
+      }
+  }
+  for (int l = 0; l < c.num_decoder_layers; ++l) {
+    // rows d..3d of multihead_attn.in_proj_weight are the K and V projections (torch MHA packing)
+    std::memcpy(host.data() + m->cross_kv_w + (size_t)l * 2 * d * d, host.data() + m->dec[l].ca_in_w + d * d, 2 * d * d * sizeof(float));
+    std::memcpy(host.data() + m->cross_kv_b + (size_t)l * 2 * d, host.data() + m->dec[l].ca_in_b + d, 2 * d * sizeof(float));
+  }
+  if (hipMemcpy(m->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    ttx_model_destroy(m);
+    return fail(TTX_ERR_HIP, "hipMemcpy of the weight blob failed");
+  }
+  *out = m;
+  return TTX_OK;
+}
+
+extern "C" void ttx_model_destroy(ttx_model* m) {
+  if (!m) return;
+  if (m->blob) (void)hipFree(m->blob);
+  delete m;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ttx_session {
+  ttx_model* m;
+  std::vector<Buf*> all;
+  // activations (shared by encoder / full decoder / step)
+  Buf x, x1, x2, xf, ao, q2, hbuf, slab, qkv, logits, ckv;
+  // sources
+  Buf tok_src, src_valid, memory, memkv;
+  // full decoder
+  Buf tok_tgt, mem_pad_tmp;
+  // loop
+  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32;
+  int* host_flag = nullptr;        // pinned, written by k_accept
+  DecState* host_state = nullptr;  // pinned copy target
+  bool attn_attr_set = false;
+  size_t attn_lds_limit = 0;
+  // profiling of the GEMM launches (bench.py roofline)
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double prof_ms = 0;
+  long long prof_launches = 0;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+  ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
+                                 &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
+                                 &kcache, &vcache, &src32}) all.push_back(b); }
+};
+
+static int ensure(Buf& b, size_t bytes, hipStream_t st) {
+  if (bytes <= b.cap) return TTX_OK;
+  if (b.p) {
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  if (hipMalloc(&b.p, want) != hipSuccess) return fail(TTX_ERR_NOMEM, "hipMalloc failed for " + std::to_string(want) + " bytes");
+  b.cap = want;
+  return TTX_OK;
+}
+
+extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
+  if (!m || !out) return fail(TTX_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->device));
+  ttx_session* s = new ttx_session();
+  s->m = m;
+  if (hipHostMalloc((void**)&s->host_flag, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc((void**)&s->host_state, sizeof(DecState), hipHostMallocDefault) != hipSuccess) {
+    delete s;
+    return fail(TTX_ERR_NOMEM, "hipHostMalloc failed");
+  }
+  *s->host_flag = 0;
+  HIP_TRY(hipEventCreate(&s->ev_a));
+  HIP_TRY(hipEventCreate(&s->ev_b));
+  HIP_TRY(hipEventCreate(&s->ev_c));
+  const char* pf = getenv("TTX_PROFILE_GEMM");
+  s->profile = pf && pf[0] == '1';
+  *out = s;
+  return TTX_OK;
+}
+
+extern "C" void ttx_session_destroy(ttx_session* s) {
+  if (!s) return;
+  (void)hipDeviceSynchronize();
+  for (Buf* b : s->all)
+    if (b->p) (void)hipFree(b->p);
+  if (s->host_flag) (void)hipHostFree(s->host_flag);
+  if (s->host_state) (void)hipHostFree(s->host_state);
+  for (auto& e : s->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (s->ev_a) (void)hipEventDestroy(s->ev_a);
+  if (s->ev_b) (void)hipEventDestroy(s->ev_b);
+  if (s->ev_c) (void)hipEventDestroy(s->ev_c);
+  delete s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launch helpers
+static int choose_splits(int Mmax, int N, int K) {
+  const int tiles = cdiv(Mmax, 64) * cdiv(N, 64);
+  int S = 1;
+  while (tiles * S < 384 && K / (S * 2) >= 64 && (K % (S * 2 * 32)) == 0 && S < 16) S *= 2;
+  return S;
+}
+
+static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* bias,
+                       float* Y, int ldy, const int* m_ptr, int Mmax, int N, int K, bool relu, int splits, long long slab_stride) {
+  if (Mmax <= 0) return TTX_OK;
+  if (K % 32) return fail(TTX_ERR_INVALID, "GEMM K must be a multiple of 32");
+  GemmArgs a;
+  a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.Y = Y; a.ldy = ldy; a.m_ptr = m_ptr;
+  a.M = Mmax; a.N = N; a.K = K; a.relu = relu ? 1 : 0;
+  a.raw = splits > 0 ? 1 : 0;
+  const int S = splits > 0 ? splits : 1;
+  a.k_per_split = K / S;
+  a.slab_stride = slab_stride;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (s->profile) {
+    if (s->ev_used == s->ev_pool.size()) {
+      hipEvent_t a0, a1;
+      HIP_TRY(hipEventCreate(&a0));
+      HIP_TRY(hipEventCreate(&a1));
+      s->ev_pool.push_back({a0, a1});
+    }
+    e0 = s->ev_pool[s->ev_used].first;
+    e1 = s->ev_pool[s->ev_used].second;
+    s->ev_used++;
+    HIP_TRY(hipEventRecord(e0, st));
+  }
+  if (Mmax <= 32) {
+    dim3 grid(cdiv(N, 128), cdiv(Mmax, 32), S);
+    hipLaunchKernelGGL((k_gemm_tn<1, 4>), grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
+    hipLaunchKernelGGL((k_gemm_tn<2, 2>), grid, dim3(256), 0, st, a);
+  }
+  if (s->profile) HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+static int launch_finish(ttx_session* s, hipStream_t st, const float* slabs, int n_slabs, long long slab_stride, const float* bias,
+                         const float* resid, const float* g1, const float* b1, const float* g2, const float* b2,
+                         const uint8_t* row_valid, float* Y, const int* m_ptr, int Mmax) {
+  if (Mmax <= 0) return TTX_OK;
+  const ttx_config& c = s->m->cfg;
+  FinishArgs a;
+  a.slabs = slabs; a.n_slabs = n_slabs; a.slab_stride = slab_stride; a.bias = bias; a.resid = resid;
+  a.g1 = g1; a.b1 = b1; a.g2 = g2; a.b2 = b2; a.row_valid = row_valid; a.Y = Y; a.m_ptr = m_ptr; a.M = Mmax;
+  a.d = c.embedding_dim; a.eps = c.layer_norm_eps;
+  dim3 grid(cdiv(Mmax, 4));
+  switch (c.embedding_dim / 64) {
+    case 1: hipLaunchKernelGGL((k_finish_ln<1>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_finish_ln<2>), grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_finish_ln<4>), grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((k_finish_ln<8>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_finish_ln<16>), grid, dim3(256), 0, st, a); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+template <int MODE>
+static int launch_attn(ttx_session* s, hipStream_t st, const AttnArgs& a, dim3 grid, int max_keys) {
+  const size_t lds = attn_lds_bytes(max_keys);
+  if (lds > 160 * 1024 - 512) return fail(TTX_ERR_INVALID, "sequence too long for the attention kernel's LDS score buffer");
+  if (lds > 64 * 1024) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  if (grid.x == 0 || grid.y == 0 || grid.z == 0) return TTX_OK;
+  hipLaunchKernelGGL((k_attn<MODE>), grid, dim3(64), lds, st, a);
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+// GEMM with N == d followed by bias + residual + LayerNorm(s): the GEMM writes split-K slabs, the finish
+// kernel reduces them.
+static int gemm_ln(ttx_session* s, hipStream_t st, const float* X, int ldx, int K, const float* W, const float* bias,
+                   const float* resid, const float* g1, const float* b1, const float* g2, const float* b2,
+                   const uint8_t* row_valid, float* Y, const int* m_ptr, int Mmax) {
+  const int d = s->m->cfg.embedding_dim;
+  const int S = choose_splits(Mmax, d, K);
+  const long long stride = (long long)Mmax * d;
+  TTX_TRY(ensure(s->slab, sizeof(float) * (size_t)S * stride, st));
+  TTX_TRY(launch_gemm(s, st, X, ldx, W, K, nullptr, s->slab.as<float>(), d, m_ptr, Mmax, d, K, false, S, stride));
+  return launch_finish(s, st, s->slab.as<float>(), S, stride, bias, resid, g1, b1, g2, b2, row_valid, Y, m_ptr, Mmax);
+}
+
+static int ensure_acts(ttx_session* s, hipStream_t st, size_t M, int qkv_layers) {
+  const ttx_config& c = s->m->cfg;
+  const size_t d = c.embedding_dim, F = c.feedforward_dim;
+  TTX_TRY(ensure(s->x, M * d * 4, st));
+  TTX_TRY(ensure(s->x1, M * d * 4, st));
+  TTX_TRY(ensure(s->x2, M * d * 4, st));
+  TTX_TRY(ensure(s->xf, M * d * 4, st));
+  TTX_TRY(ensure(s->ao, M * d * 4, st));
+  TTX_TRY(ensure(s->q2, M * d * 4, st));
+  TTX_TRY(ensure(s->hbuf, M * F * 4, st));
+  TTX_TRY(ensure(s->qkv, (size_t)qkv_layers * M * 3 * d * 4, st));
+  return TTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder: tokens int32 [B*Ls] + valid mask -> memory [B*Ls, d] (zeros at PAD rows).  modules.py:110-116
+static int run_encoder(ttx_session* s, hipStream_t st, const int* tok, const uint8_t* valid, int B, int Ls, float* memory) {
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const int d = c.embedding_dim, F = c.feedforward_dim, H = c.num_heads;
+  const int M = B * Ls;
+  TTX_TRY(ensure_acts(s, st, (size_t)M, 1));
+  float* x = s->x.as<float>();
+  float* x1 = s->x1.as<float>();
+  float* qkv = s->qkv.as<float>();
+  float* ao = s->ao.as<float>();
+  float* hb = s->hbuf.as<float>();
+  EmbedArgs e{};
+  e.table = m->p(m->src_emb); e.pe = m->p(m->pe); e.X = x; e.d = d; e.tok = tok; e.rows = M; e.L = Ls;
+  hipLaunchKernelGGL((k_embed<false>), dim3(cdiv(M, 4)), dim3(256), 0, st, e);
+  HIP_TRY(hipGetLastError());
+  for (int l = 0; l < c.num_encoder_layers; ++l) {
+    const LayerW& w = m->enc[l];
+    const bool last = (l == c.num_encoder_layers - 1);
+    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, nullptr, M, 3 * d, d, false, 0, 0));
+    AttnArgs a{};
+    a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d;
+    a.scale = 1.0f / sqrtf((float)ATT_DH); a.L = Ls; a.tok = tok; a.pad = c.pad_token;
+    TTX_TRY(launch_attn<ATT_ENC>(s, st, a, dim3(B, H, cdiv(Ls, ATT_MAXQ)), Ls));
+    TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
+                    nullptr, x1, nullptr, M));
+    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, nullptr, M, F, d, true, 0, 0));
+    TTX_TRY(gemm_ln(s, st, hb, F, F, m->p(w.l2_w), m->p(w.l2_b), x1, m->p(w.n2_w), m->p(w.n2_b),
+                    last ? m->p(m->enc_norm_w) : nullptr, last ? m->p(m->enc_norm_b) : nullptr, last ? valid : nullptr,
+                    last ? memory : x, nullptr, M));
+  }
+  return TTX_OK;
+}
+
+static int prepare_tokens(hipStream_t st, const int64_t* d_in, int* out, uint8_t* valid, int n, int pad) {
+  hipLaunchKernelGGL(k_prepare_tokens, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, out, valid, n, pad);
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+extern "C" int ttx_encode_src(ttx_session* s, const int64_t* d_src, int B, int Ls, float* d_memory, void* stream) {
+  if (!s || !d_src || !d_memory || B <= 0 || Ls <= 0) return fail(TTX_ERR_INVALID, "bad argument to ttx_encode_src");
+  if (Ls > s->m->cfg.max_positions) return fail(TTX_ERR_INVALID, "source longer than the positional table");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->m->device));
+  TTX_TRY(ensure(s->tok_src, (size_t)B * Ls * 4, st));
+  TTX_TRY(ensure(s->src_valid, (size_t)B * Ls, st));
+  TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, s->m->cfg.pad_token));
+  return run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, d_memory);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Full-prefix decoder (modules.py:118-138).  tok int32 [R*Lt]; memory fp32 [Rm*Ls, d]; mem_pad u8 [Rm*Ls].
+static int run_decoder_full(ttx_session* s, hipStream_t st, const int* tok, int R, int Lt, const float* memory,
+                            const uint8_t* mem_pad, const int* mem_row, int Rm, int Ls, float* logits) {
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const int d = c.embedding_dim, F = c.feedforward_dim, H = c.num_heads, V = c.vocab_size;
+  const int M = R * Lt, Mk = Rm * Ls;
+  TTX_TRY(ensure_acts(s, st, (size_t)M, 1));
+  TTX_TRY(ensure(s->ckv, (size_t)Mk * 2 * d * 4, st));
+  float* x = s->x.as<float>();
+  float* x1 = s->x1.as<float>();
+  float* x2 = s->x2.as<float>();
+  float* xf = s->xf.as<float>();
+  float* qkv = s->qkv.as<float>();
+  float* ao = s->ao.as<float>();
+  float* q2 = s->q2.as<float>();
+  float* hb = s->hbuf.as<float>();
+  float* ckv = s->ckv.as<float>();
+  const float scale = 1.0f / sqrtf((float)ATT_DH);
+  EmbedArgs e{};
+  e.table = m->p(m->tgt_emb); e.pe = m->p(m->pe); e.X = x; e.d = d; e.tok = tok; e.rows = M; e.L = Lt;
+  hipLaunchKernelGGL((k_embed<false>), dim3(cdiv(M, 4)), dim3(256), 0, st, e);
+  HIP_TRY(hipGetLastError());
+  for (int l = 0; l < c.num_decoder_layers; ++l) {
+    const LayerW& w = m->dec[l];
+    const bool last = (l == c.num_decoder_layers - 1);
+    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, nullptr, M, 3 * d, d, false, 0, 0));
+    AttnArgs a{};
+    a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d; a.scale = scale;
+    a.L = Lt; a.tok = tok; a.pad = c.pad_token;
+    TTX_TRY(launch_attn<ATT_FULL_SELF>(s, st, a, dim3(R, H, cdiv(Lt, ATT_MAXQ)), Lt));
+    TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
+                    nullptr, x1, nullptr, M));
+    // cross attention: Q from the decoder stream, K/V re-projected from `memory` (as the reference does per call)
+    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, nullptr, M, d, d, false, 0, 0));
+    TTX_TRY(launch_gemm(s, st, memory, d, m->p(w.ca_in_w) + (size_t)d * d, d, m->p(w.ca_in_b) + d, ckv, 2 * d, nullptr, Mk,
+                        2 * d, d, false, 0, 0));
+    AttnArgs ca{};
+    ca.q = q2; ca.ldq = d; ca.k = ckv; ca.v = ckv + d; ca.ldkv = 2 * d; ca.out = ao; ca.d = d; ca.scale = scale;
+    ca.L = Lt; ca.Lk = Ls; ca.key_pad = mem_pad; ca.mem_row = mem_row;
+    TTX_TRY(launch_attn<ATT_FULL_CROSS>(s, st, ca, dim3(R, H, cdiv(Lt, ATT_MAXQ)), Ls));
+    TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
+                    nullptr, x2, nullptr, M));
+    TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, nullptr, M, F, d, true, 0, 0));
+    TTX_TRY(gemm_ln(s, st, hb, F, F, m->p(w.l2_w), m->p(w.l2_b), x2, m->p(w.n3_w), m->p(w.n3_b),
+                    last ? m->p(m->dec_norm_w) : nullptr, last ? m->p(m->dec_norm_b) : nullptr, nullptr, last ? xf : x, nullptr, M));
+  }
+  return launch_gemm(s, st, xf, d, m->p(m->cls_w), d, m->p(m->cls_b), logits, V, nullptr, M, V, d, false, 0, 0);
+}
+
+extern "C" int ttx_decode_tgt(ttx_session* s, const int64_t* d_tgt, int R, int Lt, const float* d_memory,
+                              const uint8_t* d_mem_pad, const int32_t* d_mem_row, int Rm, int Ls, float* d_logits,
+                              void* stream) {
+  if (!s || !d_tgt || !d_memory || !d_mem_pad || !d_logits || R <= 0 || Lt <= 0 || Rm <= 0 || Ls <= 0)
+    return fail(TTX_ERR_INVALID, "bad argument to ttx_decode_tgt");
+  if (!d_mem_row && Rm != R) return fail(TTX_ERR_INVALID, "without a row map the memory must have one row per decoder row");
+  if (Lt > s->m->cfg.max_positions) return fail(TTX_ERR_INVALID, "target longer than the positional table");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->m->device));
+  TTX_TRY(ensure(s->tok_tgt, (size_t)R * Lt * 4, st));
+  TTX_TRY(prepare_tokens(st, d_tgt, s->tok_tgt.as<int>(), nullptr, R * Lt, s->m->cfg.pad_token));
+  return run_decoder_full(s, st, s->tok_tgt.as<int>(), R, Lt, d_memory, d_mem_pad, d_mem_row, Rm, Ls, d_logits);
+}
+
+__global__ void k_invert_mask(const uint8_t* valid, uint8_t* pad, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pad[i] = valid[i] ? 0 : 1;
+}
+
+extern "C" int ttx_forward(ttx_session* s, const int64_t* d_src, int B, int Ls, const int64_t* d_tgt, int Lt,
+                           float* d_logits, void* stream) {
+  if (!s || !d_src || !d_tgt || !d_logits || B <= 0 || Ls <= 0 || Lt <= 0) return fail(TTX_ERR_INVALID, "bad argument to ttx_forward");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->m->device));
+  const int d = s->m->cfg.embedding_dim;
+  TTX_TRY(ensure(s->memory, (size_t)B * Ls * d * 4, st));
+  TTX_TRY(ensure(s->mem_pad_tmp, (size_t)B * Ls, st));
+  TTX_TRY(ttx_encode_src(s, d_src, B, Ls, s->memory.as<float>(), stream));
+  hipLaunchKernelGGL(k_invert_mask, dim3(cdiv(B * Ls, 256)), dim3(256), 0, st, s->src_valid.as<uint8_t>(),
+                     s->mem_pad_tmp.as<uint8_t>(), B * Ls);
+  HIP_TRY(hipGetLastError());
+  return ttx_decode_tgt(s, d_tgt, B, Lt, s->memory.as<float>(), s->mem_pad_tmp.as<uint8_t>(), nullptr, B, Ls, d_logits, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+static int clamp_draft_len(int draft_len, int lo, int hi) { return std::min(std::max(lo, draft_len), hi); }
+
+template <typename OutT>
+static int launch_make_drafts(hipStream_t st, const int* src32, int src_ld, int off, int B, int L, int N, int D, int eos,
+                              int pad, int repl, OutT* out) {
+  const int need = N + D - 1;
+  const int Lp = L > need ? L : need;
+  const size_t lds = sizeof(int) * (size_t)(Lp + 1);
+  if (lds > 60 * 1024) return fail(TTX_ERR_INVALID, "make_drafts: padded source row too long");
+  hipLaunchKernelGGL((k_make_drafts<OutT>), dim3(B), dim3(64), lds, st, src32, src_ld, off, L, N, D, eos, pad, repl, out);
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+extern "C" int ttx_make_drafts(ttx_session* s, const int64_t* d_src, int B, int L, int draft_len, int n_drafts,
+                               int min_draft_len, int max_draft_len, int eos_token, int pad_token, int replace_token,
+                               int64_t* d_drafts, void* stream) {
+  if (!s || !d_src || !d_drafts || B <= 0 || L <= 0) return fail(TTX_ERR_INVALID, "bad argument to ttx_make_drafts");
+  // the reference's assertions (drafting.py:39-43)
+  if (n_drafts <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
+  if (min_draft_len > max_draft_len) return fail(TTX_ERR_REFERENCE, "The minimum draft length must not be greater than the maximum draft length");
+  if (pad_token == replace_token || eos_token == replace_token || eos_token == pad_token)
+    return fail(TTX_ERR_REFERENCE, "pad, eos and replace tokens must be pairwise different");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->m->device));
+  const int D = clamp_draft_len(draft_len, min_draft_len, max_draft_len);
+  if (D <= 0) return fail(TTX_ERR_INVALID, "draft length must be positive");
+  TTX_TRY(ensure(s->src32, (size_t)B * L * 4, st));
+  TTX_TRY(prepare_tokens(st, d_src, s->src32.as<int>(), nullptr, B * L, pad_token));
+  return launch_make_drafts<int64_t>(st, s->src32.as<int>(), L, 0, B, L, n_drafts, D, eos_token, pad_token, replace_token, d_drafts);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One verify step of the greedy-speculative loop: D+1 new positions per (running row, draft) through the
+// decoder with the KV cache, argmax, accept/retire, K/V commit.  Every kernel sizes its work from the
+// device-resident DecState, so the launch sequence is identical for every step (graph-replayable).
+struct StepCtx {
+  int B, Ls, N, D, Lc, gen_ld, max_len;
+  ttx_gen_params p;
+};
+
+static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k) {
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const int d = c.embedding_dim, F = c.feedforward_dim, H = c.num_heads, V = c.vocab_size, Ld = c.num_decoder_layers;
+  const int D1 = k.D + 1;
+  const int Rmax = k.B * k.N, Mmax = Rmax * D1;
+  DecState* dst = s->state.as<DecState>();
+  const int* m_ptr = &dst->m_rows;
+  float* x = s->x.as<float>();
+  float* x1 = s->x1.as<float>();
+  float* x2 = s->x2.as<float>();
+  float* xf = s->xf.as<float>();
+  float* ao = s->ao.as<float>();
+  float* q2 = s->q2.as<float>();
+  float* hb = s->hbuf.as<float>();
+  float* logits = s->logits.as<float>();
+  const float scale = 1.0f / sqrtf((float)ATT_DH);
+  const long long qkv_layer = (long long)Mmax * 3 * d;
+  const long long cache_seq = (long long)k.Lc * d;
+  const long long cache_layer = (long long)k.B * cache_seq;
+  const int qtiles = cdiv(D1, ATT_MAXQ);
+
+  EmbedArgs e{};
+  e.table = m->p(m->tgt_emb); e.pe = m->p(m->pe); e.X = x; e.d = d;
+  e.st = dst; e.act_idx = s->act_idx.as<int>(); e.front = s->front.as<int>(); e.gen = s->gen.as<int>(); e.gen_ld = k.gen_ld;
+  e.drafts = s->drafts.as<int>(); e.N = k.N; e.D = k.D;
+  hipLaunchKernelGGL((k_embed<true>), dim3(cdiv(Mmax, 4)), dim3(256), 0, st, e);
+  HIP_TRY(hipGetLastError());
+
+  for (int l = 0; l < Ld; ++l) {
+    const LayerW& w = m->dec[l];
+    const bool last = (l == Ld - 1);
+    float* qkv = s->qkv.as<float>() + (size_t)l * qkv_layer;
+    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, m_ptr, Mmax, 3 * d, d, false, 0, 0));
+    AttnArgs a{};
+    a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d; a.scale = scale;
+    a.tok = s->gen.as<int>(); a.pad = c.pad_token; a.st = dst; a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>();
+    a.kcache = s->kcache.as<float>() + (size_t)l * cache_layer; a.vcache = s->vcache.as<float>() + (size_t)l * cache_layer;
+    a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D1 = D1;
+    TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, dim3(Rmax, H, qtiles), k.Lc));
+    TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
+                    nullptr, x1, m_ptr, Mmax));
+    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, m_ptr, Mmax, d, d, false, 0, 0));
+    AttnArgs ca{};
+    ca.q = q2; ca.ldq = d; ca.k = s->memkv.as<float>() + (size_t)l * 2 * d; ca.v = ca.k + d; ca.ldkv = Ld * 2 * d;
+    ca.out = ao; ca.d = d; ca.scale = scale; ca.Lk = k.Ls; ca.key_pad = s->src_valid.as<uint8_t>();
+    ca.st = dst; ca.act_idx = s->act_idx.as<int>(); ca.front = s->front.as<int>(); ca.N = k.N; ca.D1 = D1;
+    TTX_TRY(launch_attn<ATT_STEP_CROSS>(s, st, ca, dim3(Rmax, H, qtiles), k.Ls));
+    TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
+                    nullptr, x2, m_ptr, Mmax));
+    TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, m_ptr, Mmax, F, d, true, 0, 0));
+    TTX_TRY(gemm_ln(s, st, hb, F, F, m->p(w.l2_w), m->p(w.l2_b), x2, m->p(w.n3_w), m->p(w.n3_b),
+                    last ? m->p(m->dec_norm_w) : nullptr, last ? m->p(m->dec_norm_b) : nullptr, nullptr, last ? xf : x, m_ptr, Mmax));
+  }
+  TTX_TRY(launch_gemm(s, st, xf, d, m->p(m->cls_w), d, m->p(m->cls_b), logits, V, m_ptr, Mmax, V, d, false, 0, 0));
+  hipLaunchKernelGGL(k_argmax, dim3(cdiv(Mmax, 4)), dim3(256), 0, st, logits, V, s->pred.as<int>(), m_ptr, Mmax);
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+struct GenCtx {
+  StepCtx k;
+  LoopArgs la;
+  KvCopyArgs kc;
+};
+
+static int launch_accept_and_commit(ttx_session* s, hipStream_t st, const GenCtx& g) {
+  hipLaunchKernelGGL(k_accept, dim3(1), dim3(256), 0, st, g.la);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_kvcopy, dim3(g.k.B, s->m->cfg.num_decoder_layers), dim3(256), 0, st, g.kc);
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+extern "C" int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_src, int B, int Ls,
+                                               const ttx_gen_params* p, int64_t* d_out, ttx_gen_stats* stats,
+                                               void* stream) {
+  if (!s || !d_src || !p || !d_out || B <= 0 || Ls <= 1) return fail(TTX_ERR_INVALID, "bad argument to ttx_greedy_speculative_generate");
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  if (p->n_drafts <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
+  if (p->max_len < 1) return fail(TTX_ERR_REFERENCE, "The minimum draft length must not be greater than the maximum draft length");
+  if (p->pad_token == p->replace_token || p->eos_token == p->replace_token || p->eos_token == p->pad_token)
+    return fail(TTX_ERR_REFERENCE, "pad, eos and replace tokens must be pairwise different");
+  if (p->draft_len <= 0) return fail(TTX_ERR_REFERENCE, "Number of speculative tokens must be a positive integer.");
+  if (p->draft_len > p->max_len) return fail(TTX_ERR_REFERENCE, "draft_len beyond max_len: the reference's scatter shapes disagree");
+  if (p->pad_token != c.pad_token) return fail(TTX_ERR_INVALID, "generator pad token differs from the model's");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(m->device));
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
+  const int N = p->n_drafts, D = p->draft_len, D1 = D + 1;
+  const int max_len = p->max_len;
+  if (max_len + D + 2 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len + draft_len exceeds the positional table");
+
+  GenCtx g{};
+  g.k.B = B; g.k.Ls = Ls; g.k.N = N; g.k.D = D; g.k.max_len = max_len; g.k.p = *p;
+  g.k.Lc = max_len + D1;           // cache positions per row (front + D < max_len + D)
+  g.k.gen_ld = max_len + D + 2;
+  const size_t Mmax = (size_t)B * N * D1;
+
+  TTX_TRY(ensure(s->tok_src, (size_t)B * Ls * 4, st));
+  TTX_TRY(ensure(s->src_valid, (size_t)B * Ls, st));
+  TTX_TRY(ensure(s->memory, (size_t)B * Ls * d * 4, st));
+  TTX_TRY(ensure(s->memkv, (size_t)B * Ls * Ld * 2 * d * 4, st));
+  TTX_TRY(ensure(s->drafts, (size_t)B * N * D * 4, st));
+  TTX_TRY(ensure(s->gen, (size_t)B * g.k.gen_ld * 4, st));
+  TTX_TRY(ensure(s->front, (size_t)B * 4, st));
+  TTX_TRY(ensure(s->act_idx, (size_t)B * 4, st));
+  TTX_TRY(ensure(s->rec, (size_t)B * sizeof(CopyRec), st));
+  TTX_TRY(ensure(s->pred, Mmax * 4, st));
+  TTX_TRY(ensure(s->state, sizeof(DecState), st));
+  TTX_TRY(ensure(s->logits, Mmax * V * 4, st));
+  TTX_TRY(ensure(s->kcache, (size_t)Ld * B * g.k.Lc * d * 4, st));
+  TTX_TRY(ensure(s->vcache, (size_t)Ld * B * g.k.Lc * d * 4, st));
+  // the encoder and the step share the activation buffers; size them for the larger of the two
+  TTX_TRY(ensure_acts(s, st, std::max(Mmax, (size_t)B * Ls), 1));
+  TTX_TRY(ensure(s->qkv, std::max((size_t)Ld * Mmax, (size_t)B * Ls) * 3 * d * 4, st));
+
+  s->ev_used = 0;
+  HIP_TRY(hipEventRecord(s->ev_a, st));
+  // encoder once per batch (:60-61) + cross-attention K/V of every decoder layer once per source
+  TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
+  TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));
+  TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv.as<float>(),
+                      Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0));
+  // drafts from src[:, 1:] (:64-73): min_draft_len 1, max_draft_len max_len
+  TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls, 1, B, Ls - 1, N, D, p->eos_token, p->pad_token,
+                                  p->replace_token, s->drafts.as<int>()));
+
+  g.la.st = s->state.as<DecState>(); g.la.act_idx = s->act_idx.as<int>(); g.la.front = s->front.as<int>();
+  g.la.gen = s->gen.as<int>(); g.la.gen_ld = g.k.gen_ld; g.la.drafts = s->drafts.as<int>(); g.la.pred = s->pred.as<int>();
+  g.la.rec = s->rec.as<CopyRec>(); g.la.out = d_out;
+  int* dev_flag = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&dev_flag, s->host_flag, 0));
+  g.la.host_flag = dev_flag;
+  g.la.B = B; g.la.N = N; g.la.D = D; g.la.Ls = Ls; g.la.max_len = max_len; g.la.pad = p->pad_token; g.la.bos = p->bos_token;
+  g.la.eos = p->eos_token;
+  g.kc.st = s->state.as<DecState>(); g.kc.rec = s->rec.as<CopyRec>(); g.kc.qkv = s->qkv.as<float>();
+  g.kc.qkv_layer_stride = (long long)Mmax * 3 * d;
+  g.kc.kcache = s->kcache.as<float>(); g.kc.vcache = s->vcache.as<float>();
+  g.kc.cache_seq_stride = (long long)g.k.Lc * d; g.kc.cache_layer_stride = (long long)B * g.k.Lc * d;
+  g.kc.N = N; g.kc.D1 = D1; g.kc.d = d;
+
+  *s->host_flag = 0;
+  hipLaunchKernelGGL(k_loop_init, dim3(64), dim3(256), 0, st, g.la);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev_b, st));
+
+  // Host loop: at most `max_len` verify steps can ever be needed (every step appends >= 1 token).
+  int launched = 0;
+  for (;;) {
+    HIP_TRY(hipStreamSynchronize(st));
+    if (*s->host_flag) break;
+    if (launched > max_len + 2) return fail(TTX_ERR_HIP, "greedy-speculative loop failed to terminate");
+    TTX_TRY(run_step(s, st, g.k));
+    TTX_TRY(launch_accept_and_commit(s, st, g));
+    ++launched;
+  }
+  HIP_TRY(hipEventRecord(s->ev_c, st));
+  HIP_TRY(hipMemcpyAsync(s->host_state, s->state.as<DecState>(), sizeof(DecState), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const DecState& hs = *s->host_state;
+  if (stats) {
+    stats->model_calls = hs.steps;
+    stats->accepted_tokens = hs.accepted;
+    stats->produced_tokens = hs.produced;
+    stats->verified_positions = hs.verified_positions;
+    stats->kv_prefix_positions = hs.kv_prefix_positions;
+    stats->src_positions = hs.src_positions;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_a, s->ev_b));
+    stats->encode_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_b, s->ev_c));
+    stats->decode_ms = ms;
+  }
+  if (s->profile) {
+    s->prof_ms = 0;
+    s->prof_launches = (long long)s->ev_used;
+    for (size_t i = 0; i < s->ev_used; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) s->prof_ms += ms;
+    }
+  }
+  if (hs.error) return fail(TTX_ERR_REFERENCE, "a row finished at a width beyond max_len: shape mismatch in the reference (speculative_decoding.py:158)");
+  return TTX_OK;
+}
+
+extern "C" int ttx_greedy_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p,
+                                   int64_t* d_out, ttx_gen_stats* stats, void* stream) {
+  (void)s; (void)d_src; (void)B; (void)Ls; (void)p; (void)d_out; (void)stats; (void)stream;
+  return fail(TTX_ERR_INVALID, "ttx_greedy_generate: not built yet in this revision");
+}
+
+extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches) {
+  if (!s) return fail(TTX_ERR_INVALID, "null session");
+  if (gemm_ms) *gemm_ms = s->prof_ms;
+  if (gemm_launches) *gemm_launches = s->prof_launches;
+  return TTX_OK;
+}

@@ -1,0 +1,642 @@
+// Device code of libttx_hip.so — hand-written HIP for gfx950 (CDNA4, wave64).  fp32 throughout:
+// the reference runs with `precision: null` (configs/cfg_standard_product_prediction.yaml:7) and the
+// parity bar is token identity, so the dense contractions use the f32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 fma chain), not a reduced-precision format.
+//
+// Kernel inventory:
+//   k_gemm_tn        K2/K5/K6/K8  Y = act(X·Wᵀ + b) or raw split-K slabs; LDS-staged 32-deep K tiles,
+//                                 one 32x32 MFMA accumulator tile per wave
+//   k_finish_ln      K5/K6/K7     sum of split-K slabs + bias + residual + LayerNorm (+ final stack norm)
+//   k_attn<mode>     K3/K4        small-sequence attention, one wave per (row, head, <=16 queries),
+//                                 wavefront-shuffle softmax; KV-cache + in-flight draft keys
+//   k_embed_*        K1           token embedding + sinusoid row (pos + 1)
+//   k_argmax         K8           wavefront-shuffle argmax over the vocabulary
+//   k_make_drafts    K9           sliding-window drafts with the reference's fp32 index spacing
+//   k_accept / k_kvcopy  K10      verify + accept + retire + active-row compaction on the device
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ttx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// Device-resident loop state of one generate call (one per session).
+struct DecState {
+  int n_active;        // Bc: rows still decoding
+  int r_rows;          // Bc * N
+  int m_rows;          // Bc * N * (D+1): rows of this step's GEMMs
+  int stop;            // loop finished
+  int width;           // the reference's generated_tokens.size(1)
+  int steps;           // decoder calls so far (model_calls_num)
+  int error;           // 1: a row finished at width > max_len (the reference raises there)
+  int n_copy;          // rows whose accepted K/V must be copied into the cache after this step
+  long long accepted, produced, verified_positions, kv_prefix_positions, src_positions;
+};
+
+struct CopyRec { int b, best, nacc, front_old; };
+
+// ------------------------------------------------------------------------------------------------
+// GEMM:  Y[m, n] = sum_k X[m, k] * W[n, k]   (torch.nn.Linear layout: both operands K-contiguous)
+struct GemmArgs {
+  const float* X; int ldx;
+  const float* W; int ldw;
+  const float* bias;         // may be null
+  float* Y; int ldy;
+  const int* m_ptr;          // device-resident row count (null: use M)
+  int M, N, K;
+  int k_per_split;           // K range handled by one blockIdx.z
+  int relu;                  // epilogue
+  int raw;                   // 1: write un-biased partial sums to slab blockIdx.z
+  long long slab_stride;     // floats between slabs
+};
+
+template <int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_tn(GemmArgs a) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int BM = 32 * WGM, BN = 32 * WGN, BK = 32, LDT = BK + 4;
+  constexpr int RPP = NT / 8;                 // tile rows filled per pass (8 float4 per 32-float row)
+  constexpr int AP = BM / RPP, BP = BN / RPP;
+  static_assert(AP >= 1 && BP >= 1, "tile too small for the thread count");
+  __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (m0 >= M) return;
+  const int kbeg = blockIdx.z * a.k_per_split;
+  const int kend = min(a.K, kbeg + a.k_per_split);
+
+  const int t = threadIdx.x;
+  const int lr = t >> 3, lc = (t & 7) * 4;
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r = lane & 31, h = lane >> 5;
+
+  float4 ra[AP], rb[BP];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const int row = m0 + p * RPP + lr;
+      ra[p] = (row < M) ? *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + k0 + lc)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      const int col = n0 + p * RPP + lr;
+      rb[p] = (col < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)col * a.ldw + k0 + lc)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  gload(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+    for (int p = 0; p < AP; ++p) *reinterpret_cast<float4*>(&As[(p * RPP + lr) * LDT + lc]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < BP; ++p) *reinterpret_cast<float4*>(&Bs[(p * RPP + lr) * LDT + lc]) = rb[p];
+    __syncthreads();
+    if (k0 + BK < kend) gload(k0 + BK);       // next tile's HBM/L2 latency hides under this tile's MFMAs
+    const float* ap = &As[(wm * 32 + r) * LDT + 4 * h];
+    const float* bp = &Bs[(wn * 32 + r) * LDT + 4 * h];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      // lanes 0-31 feed k = kk..kk+3, lanes 32-63 feed k = kk+4..kk+7 (same permutation on both
+      // operands, so each MFMA sums two matching k's)
+      const float4 av = *reinterpret_cast<const float4*>(ap + kk);
+      const float4 bv = *reinterpret_cast<const float4*>(bp + kk);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)
+  float* Y = a.Y + (a.raw ? (size_t)blockIdx.z * a.slab_stride : 0);
+  const int col = n0 + wn * 32 + r;
+  if (col < a.N) {
+    const float bv = (!a.raw && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = m0 + wm * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+      if (row < M) {
+        float val = acc[v] + bv;
+        if (a.relu) val = fmaxf(val, 0.f);
+        Y[(size_t)row * a.ldy + col] = val;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave reductions (64 lanes).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = LN2?( LN( resid + bias + sum_s slab[s] ) ) — one wave per row, VPL contiguous values per lane.
+struct FinishArgs {
+  const float* slabs; int n_slabs; long long slab_stride;
+  const float* bias;
+  const float* resid;          // [M, d]
+  const float* g1; const float* b1;
+  const float* g2; const float* b2;   // optional second LayerNorm (final stack norm), may be null
+  const uint8_t* row_valid;    // optional: rows with 0 are written as zeros
+  float* Y;
+  const int* m_ptr; int M; int d; float eps;
+};
+
+template <int VPL>
+__device__ __forceinline__ void ln_inplace(float (&x)[VPL], const float* g, const float* b, int c0, int d, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) s += x[i];
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) { const float t = x[i] - mean; q += t * t; }
+  const float var = wave_sum(q) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) x[i] = (x[i] - mean) * rstd * g[c0 + i] + b[c0 + i];
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void k_finish_ln(FinishArgs a) {
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * VPL;
+  float x[VPL];
+  const size_t off = (size_t)row * a.d + c0;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) x[i] = a.resid[off + i] + a.bias[c0 + i];
+  for (int s = 0; s < a.n_slabs; ++s) {
+    const float* p = a.slabs + (size_t)s * a.slab_stride + off;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) x[i] += p[i];
+  }
+  ln_inplace<VPL>(x, a.g1, a.b1, c0, a.d, a.eps);
+  if (a.g2) ln_inplace<VPL>(x, a.g2, a.b2, c0, a.d, a.eps);
+  const bool keep = a.row_valid ? (a.row_valid[row] != 0) : true;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) a.Y[off + i] = keep ? x[i] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention.  One wave per (row, head, tile of <= MAXQ queries).  Keys come in two segments:
+//   A: `nA` keys every query may see (KV cache prefix / encoder memory), individually maskable;
+//   B: `nB` keys with the causal rule  key j visible to query i  <=>  j <= qpos0 + i.
+// Scores live in LDS as S[key][MAXQ+1]; softmax by wavefront shuffles; P·V with lane = head dim.
+constexpr int ATT_DH = 32;
+constexpr int ATT_MAXQ = 16;
+constexpr int ATT_SQ = ATT_MAXQ + 1;
+
+__host__ __device__ inline size_t attn_lds_bytes(int max_keys) {
+  return sizeof(float) * ((size_t)ATT_MAXQ * ATT_DH + (size_t)max_keys * ATT_SQ + ATT_MAXQ);
+}
+
+template <class VA, class VB>
+__device__ __forceinline__ void attn_core(const float* __restrict__ q, int ldq, int nq,
+                                          const float* __restrict__ kA, const float* __restrict__ vA, int ldA, int nA, VA validA,
+                                          const float* __restrict__ kB, const float* __restrict__ vB, int ldB, int nB, int qpos0, VB validB,
+                                          float* __restrict__ out, int ldo, float scale, float* lds) {
+  const int lane = threadIdx.x & 63;
+  float* Qs = lds;                               // [MAXQ][DH]
+  float* S = lds + ATT_MAXQ * ATT_DH;            // [nk][SQ]
+  const int nk = nA + nB;
+  float* inv = S + (size_t)nk * ATT_SQ;          // [MAXQ]
+
+  for (int e = lane * 4; e < nq * ATT_DH; e += 256) {
+    const int i = e / ATT_DH, c = e % ATT_DH;
+    *reinterpret_cast<float4*>(&Qs[i * ATT_DH + c]) = *reinterpret_cast<const float4*>(q + (size_t)i * ldq + c);
+  }
+  __syncthreads();
+
+  // phase 1: scores, lane <-> key
+  for (int c0 = 0; c0 < nk; c0 += 64) {
+    const int key = c0 + lane;
+    if (key < nk) {
+      const float* kp;
+      bool ok;
+      int jb = -1;
+      if (key < nA) { kp = kA + (size_t)key * ldA; ok = validA(key); }
+      else { jb = key - nA; kp = kB + (size_t)jb * ldB; ok = validB(jb); }
+      float4 kr[ATT_DH / 4];
+#pragma unroll
+      for (int c = 0; c < ATT_DH / 4; ++c) kr[c] = *reinterpret_cast<const float4*>(kp + 4 * c);
+      for (int i = 0; i < nq; ++i) {
+        const float4* qv = reinterpret_cast<const float4*>(&Qs[i * ATT_DH]);
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < ATT_DH / 4; ++c) {
+          const float4 qq = qv[c];
+          dot = fmaf(kr[c].x, qq.x, dot); dot = fmaf(kr[c].y, qq.y, dot);
+          dot = fmaf(kr[c].z, qq.z, dot); dot = fmaf(kr[c].w, qq.w, dot);
+        }
+        const bool vis = ok && (jb < 0 || jb <= qpos0 + i);
+        S[(size_t)key * ATT_SQ + i] = vis ? dot * scale : -INFINITY;
+      }
+    }
+  }
+  __syncthreads();
+
+  // phase 2: softmax over keys, one query at a time
+  for (int i = 0; i < nq; ++i) {
+    float m = -INFINITY;
+    for (int key = lane; key < nk; key += 64) m = fmaxf(m, S[(size_t)key * ATT_SQ + i]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int key = lane; key < nk; key += 64) {
+      const float s = S[(size_t)key * ATT_SQ + i];
+      const float p = (s == -INFINITY) ? 0.f : expf(s - m);
+      S[(size_t)key * ATT_SQ + i] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) inv[i] = sum > 0.f ? 1.0f / sum : 0.f;
+  }
+  __syncthreads();
+
+  // phase 3: out[i][d] = sum_key P[i][key] V[key][d]; lane = d + 32 * (key parity)
+  const int d = lane & 31, half = lane >> 5;
+  float acc[ATT_MAXQ];
+#pragma unroll
+  for (int i = 0; i < ATT_MAXQ; ++i) acc[i] = 0.f;
+#pragma unroll 4
+  for (int key = half; key < nk; key += 2) {
+    const float* vp = (key < nA) ? (vA + (size_t)key * ldA) : (vB + (size_t)(key - nA) * ldB);
+    const float v = vp[d];
+    const float* pr = &S[(size_t)key * ATT_SQ];
+#pragma unroll
+    for (int i = 0; i < ATT_MAXQ; ++i)
+      if (i < nq) acc[i] = fmaf(pr[i], v, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < ATT_MAXQ; ++i) acc[i] += __shfl_xor(acc[i], 32, 64);
+  if (half == 0) {
+#pragma unroll
+    for (int i = 0; i < ATT_MAXQ; ++i)
+      if (i < nq) out[(size_t)i * ldo + d] = acc[i] * inv[i];
+  }
+}
+
+enum AttnMode { ATT_ENC = 0, ATT_FULL_SELF = 1, ATT_FULL_CROSS = 2, ATT_STEP_SELF = 3, ATT_STEP_CROSS = 4 };
+
+struct AttnArgs {
+  const float* q; int ldq;         // query rows (packed QKV buffer or a plain [M,d] buffer)
+  const float* k; const float* v; int ldkv;   // segment-B / encoder keys (packed QKV buffer) or cross K/V
+  float* out; int d;               // [M, d]
+  float scale;
+  int L;                           // ENC: Ls; FULL_*: Lt (queries per row)
+  int Lk;                          // FULL_CROSS / STEP_CROSS: Ls
+  const int* tok; int pad;         // ENC: src tokens [B,Ls]; FULL_SELF: tgt tokens [R,Lt]; STEP_SELF: gen [B, gen_ld]
+  const uint8_t* key_pad;          // FULL_CROSS: [Rm, Ls] 1 = PAD key; STEP_CROSS/ENC: src_valid (1 = real token)
+  const int* mem_row;              // FULL_CROSS: decoder row -> memory row (null: identity)
+  // step modes
+  const DecState* st; const int* act_idx; const int* front;
+  const float* kcache; const float* vcache; long long cache_seq_stride;  // floats per sequence in the cache
+  int gen_ld; int N; int D1;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_attn(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int h = blockIdx.y;
+  const int q0 = blockIdx.z * ATT_MAXQ;
+  const int hd = h * ATT_DH;
+  auto never = [](int) { return true; };
+
+  if constexpr (MODE == ATT_ENC) {
+    const int b = blockIdx.x;
+    const int nq = min(ATT_MAXQ, a.L - q0);
+    if (nq <= 0) return;
+    const size_t row0 = (size_t)b * a.L;
+    const int* tk = a.tok + row0;
+    const int pad = a.pad;
+    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
+              a.k + row0 * a.ldkv + hd, a.v + row0 * a.ldkv + hd, a.ldkv, a.L,
+              [=](int key) { return tk[key] != pad; },
+              (const float*)nullptr, (const float*)nullptr, 0, 0, 0, never,
+              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+  } else if constexpr (MODE == ATT_FULL_SELF) {
+    const int rr = blockIdx.x;
+    const int nq = min(ATT_MAXQ, a.L - q0);
+    if (nq <= 0) return;
+    const size_t row0 = (size_t)rr * a.L;
+    const int* tk = a.tok + row0;
+    const int pad = a.pad;
+    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
+              (const float*)nullptr, (const float*)nullptr, 0, 0, never,
+              a.k + row0 * a.ldkv + hd, a.v + row0 * a.ldkv + hd, a.ldkv, min(a.L, q0 + nq), q0,
+              [=](int j) { return tk[j] != pad; },
+              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+  } else if constexpr (MODE == ATT_FULL_CROSS) {
+    const int rr = blockIdx.x;
+    const int nq = min(ATT_MAXQ, a.L - q0);
+    if (nq <= 0) return;
+    const size_t row0 = (size_t)rr * a.L;
+    const int mr = a.mem_row ? a.mem_row[rr] : rr;
+    const size_t mrow0 = (size_t)mr * a.Lk;
+    const uint8_t* kp = a.key_pad + mrow0;
+    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
+              a.k + mrow0 * a.ldkv + hd, a.v + mrow0 * a.ldkv + hd, a.ldkv, a.Lk,
+              [=](int key) { return kp[key] == 0; },
+              (const float*)nullptr, (const float*)nullptr, 0, 0, 0, never,
+              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+  } else if constexpr (MODE == ATT_STEP_SELF) {
+    const int rr = blockIdx.x;                   // slot * N + n
+    if (rr >= a.st->r_rows) return;
+    const int nq = min(ATT_MAXQ, a.D1 - q0);
+    if (nq <= 0) return;
+    const int b = a.act_idx[rr / a.N];
+    const int f = a.front[b];
+    const size_t row0 = (size_t)rr * a.D1;
+    const int* tk = a.tok + (size_t)b * a.gen_ld;
+    const int pad = a.pad;
+    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
+              a.kcache + (size_t)b * a.cache_seq_stride + hd, a.vcache + (size_t)b * a.cache_seq_stride + hd, a.d, f,
+              [=](int key) { return tk[key] != pad; },
+              a.k + row0 * a.ldkv + hd, a.v + row0 * a.ldkv + hd, a.ldkv, min(a.D1, q0 + nq), q0,
+              [=](int j) { return j > 0 || tk[f] != pad; },
+              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+  } else {  // ATT_STEP_CROSS
+    const int rr = blockIdx.x;
+    if (rr >= a.st->r_rows) return;
+    const int nq = min(ATT_MAXQ, a.D1 - q0);
+    if (nq <= 0) return;
+    const int b = a.act_idx[rr / a.N];
+    const size_t row0 = (size_t)rr * a.D1;
+    const size_t mrow0 = (size_t)b * a.Lk;
+    const uint8_t* kv = a.key_pad + mrow0;
+    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
+              a.k + mrow0 * a.ldkv + hd, a.v + mrow0 * a.ldkv + hd, a.ldkv, a.Lk,
+              [=](int key) { return kv[key] != 0; },
+              (const float*)nullptr, (const float*)nullptr, 0, 0, 0, never,
+              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding + positional row (pos + 1); one wave per token row, float4 per lane when d == 256.
+struct EmbedArgs {
+  const float* table; const float* pe; float* X; int d;
+  // full mode: tokens int32 [rows], position = row % L
+  const int* tok; int rows; int L;
+  // step mode
+  const DecState* st; const int* act_idx; const int* front; const int* gen; int gen_ld;
+  const int* drafts; int N; int D;   // drafts int32 [B, N, D]
+};
+
+template <bool STEP>
+__global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  int tok, pos;
+  if constexpr (STEP) {
+    if (row >= a.st->m_rows) return;
+    const int D1 = a.D + 1;
+    const int j = row % D1;
+    const int rn = row / D1;
+    const int n = rn % a.N;
+    const int b = a.act_idx[rn / a.N];
+    const int f = a.front[b];
+    tok = (j == 0) ? a.gen[(size_t)b * a.gen_ld + f] : a.drafts[((size_t)b * a.N + n) * a.D + (j - 1)];
+    pos = f + j;
+  } else {
+    if (row >= a.rows) return;
+    tok = a.tok[row];
+    pos = row % a.L;
+  }
+  const float* e = a.table + (size_t)tok * a.d;
+  const float* p = a.pe + (size_t)(pos + 1) * a.d;
+  float* x = a.X + (size_t)row * a.d;
+  for (int c = lane * 4; c < a.d; c += 256) {
+    const float4 ev = *reinterpret_cast<const float4*>(e + c);
+    const float4 pv = *reinterpret_cast<const float4*>(p + c);
+    *reinterpret_cast<float4*>(x + c) = make_float4(ev.x + pv.x, ev.y + pv.y, ev.z + pv.z, ev.w + pv.w);
+  }
+}
+
+// int64 -> int32 tokens, plus the "real token" byte mask
+__global__ void k_prepare_tokens(const int64_t* in, int* out, uint8_t* valid, int n, int pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int t = (int)in[i];
+    out[i] = t;
+    if (valid) valid[i] = (t != pad) ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// argmax over the vocabulary, one wave per row; first maximum wins (torch.argmax on CPU).
+__global__ __launch_bounds__(256) void k_argmax(const float* logits, int V, int* pred, const int* m_ptr, int M) {
+  const int rows = m_ptr ? *m_ptr : M;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = logits + (size_t)row * V;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < V; c += 64) {
+    const float v = p[c];
+    if (v > best) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) pred[row] = bi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// make_drafts (src/utils/drafting.py:45-67).  One block per source row; `off` skips leading tokens
+// (the generators pass src[:, 1:]).  The window index is  (int)( float(i) * (float(take-1) / float(max(N-1,1))) )
+// evaluated in fp32 with round-to-nearest multiplies/divides and no contraction, as torch does.
+template <typename OutT>
+__global__ __launch_bounds__(64) void k_make_drafts(const int* src, int src_ld, int off, int L, int N, int D,
+                                                    int eos, int pad, int repl, OutT* out) {
+  extern __shared__ int pre[];                   // service-token prefix sums over the padded row, [Lp + 1]
+  const int b = blockIdx.x;
+  const int need = N + D - 1;
+  const int Lp = L > need ? L : need;
+  const int W = Lp - D + 1;
+  const int* s = src + (size_t)b * src_ld + off;
+  __shared__ int n_clean;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    pre[0] = 0;
+    for (int i = 0; i < Lp; ++i) {
+      const int t = (i < L) ? s[i] : pad;
+      c += (t == eos || t == pad) ? 1 : 0;
+      pre[i + 1] = c;
+    }
+    int clean = 0;
+    for (int w = 0; w < W; ++w) clean += (pre[w + D] - pre[w] == 0) ? 1 : 0;
+    n_clean = clean;
+  }
+  __syncthreads();
+  const int take = n_clean > N ? n_clean : N;
+  const float ratio = __fdiv_rn((float)(take - 1), (float)(N - 1 > 1 ? N - 1 : 1));
+  for (int e = threadIdx.x; e < N * D; e += blockDim.x) {
+    const int i = e / D, j = e % D;
+    int w = (int)__fmul_rn((float)i, ratio);
+    if (w > W - 1) w = W - 1;
+    const int p = w + j;
+    int t = (p < L) ? s[p] : pad;
+    if (t == eos || t == pad) t = repl;
+    out[((size_t)b * N + i) * D + e % D] = (OutT)t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Greedy-speculative bookkeeping (speculative_decoding.py:93-171) on the device.
+struct LoopArgs {
+  DecState* st; int* act_idx; int* front; int* gen; int gen_ld;
+  const int* drafts; const int* pred;
+  CopyRec* rec; int64_t* out; int* host_flag;
+  int B, N, D, Ls, max_len, pad, bos, eos;
+};
+
+__global__ void k_loop_init(LoopArgs a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = a.B * a.gen_ld;
+  for (int i = tid; i < total; i += gridDim.x * blockDim.x) a.gen[i] = (i % a.gen_ld == 0) ? a.bos : a.pad;
+  for (int i = tid; i < a.B * a.max_len; i += gridDim.x * blockDim.x) a.out[i] = a.pad;
+  for (int i = tid; i < a.B; i += gridDim.x * blockDim.x) { a.act_idx[i] = i; a.front[i] = 0; }
+  if (tid == 0) {
+    DecState s;
+    s.n_active = a.B; s.r_rows = a.B * a.N; s.m_rows = a.B * a.N * (a.D + 1);
+    s.width = 1; s.steps = 0; s.error = 0; s.n_copy = 0;
+    s.stop = (1 >= a.max_len) ? 1 : 0;          // `while generated_tokens.size(1) < max_len` (:93)
+    if (s.stop) { s.n_active = 0; s.r_rows = 0; s.m_rows = 0; }
+    s.accepted = s.produced = s.verified_positions = s.kv_prefix_positions = s.src_positions = 0;
+    *a.st = s;
+    *a.host_flag = s.stop;
+  }
+}
+
+// One block.  Verify each draft against the argmax tokens, keep the longest accepted prefix plus one
+// bonus token, retire rows that produced EOS, compact the active list, decide whether the loop goes on.
+__global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
+  __shared__ int s_maxfront, s_anyfin;
+  __shared__ long long s_acc, s_prefix;
+  DecState* st = a.st;
+  const int Bc = st->n_active;
+  if (Bc == 0) return;
+  const int D1 = a.D + 1;
+  if (threadIdx.x == 0) { s_maxfront = 0; s_anyfin = 0; s_acc = 0; s_prefix = 0; }
+  __syncthreads();
+  for (int slot = threadIdx.x; slot < Bc; slot += blockDim.x) {
+    const int b = a.act_idx[slot];
+    const int f = a.front[b];
+    int best = 0, bacc = -1;
+    for (int n = 0; n < a.N; ++n) {
+      const int* dr = a.drafts + ((size_t)b * a.N + n) * a.D;
+      const int* pr = a.pred + ((size_t)slot * a.N + n) * D1;
+      int acc = 0;
+      while (acc < a.D && dr[acc] == pr[acc]) ++acc;
+      if (acc > bacc) { bacc = acc; best = n; }
+    }
+    const int* pr = a.pred + ((size_t)slot * a.N + best) * D1;
+    int* g = a.gen + (size_t)b * a.gen_ld;
+    bool fin = false;
+    for (int j = 0; j <= bacc; ++j) {
+      const int t = pr[j];
+      g[f + 1 + j] = t;
+      fin |= (t == a.eos);
+    }
+    a.front[b] = f + bacc + 1;
+    a.rec[slot] = CopyRec{b, best, bacc, f};
+    // the reference tests the whole row for EOS (:149); earlier positions can only hold EOS if the
+    // model emitted it as a non-final accepted token, which the per-step test above already caught
+    a.rec[slot].b = fin ? -(b + 1) : b;          // negative marks "finished this step"
+    atomicMax(&s_maxfront, f);
+    atomicAdd((unsigned long long*)&s_acc, (unsigned long long)bacc);
+    atomicAdd((unsigned long long*)&s_prefix, (unsigned long long)f);
+    if (fin) s_anyfin = 1;
+  }
+  __syncthreads();
+  const int width = s_maxfront + 1 + D1;          // columns of generated_tokens after this step (:97-102,:145)
+  const int wcopy = width < a.max_len ? width : a.max_len;
+  // finished rows -> output (:158)
+  for (int slot = 0; slot < Bc; ++slot) {
+    const int code = a.rec[slot].b;
+    if (code < 0) {
+      const int b = -code - 1;
+      const int* g = a.gen + (size_t)b * a.gen_ld;
+      for (int c = threadIdx.x; c < wcopy; c += blockDim.x) a.out[(size_t)b * a.max_len + c] = g[c];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int nn = 0;
+    for (int slot = 0; slot < Bc; ++slot) {
+      const int code = a.rec[slot].b;
+      if (code >= 0) a.act_idx[nn++] = code;
+      else a.rec[slot].b = -code - 1;
+    }
+    st->n_copy = Bc;
+    st->steps += 1;
+    st->accepted += s_acc;
+    st->produced += s_acc + Bc;
+    st->verified_positions += (long long)Bc * a.N * D1;
+    st->kv_prefix_positions += s_prefix;
+    st->src_positions += (long long)Bc * a.Ls;
+    st->width = width;
+    if (s_anyfin && width > a.max_len) st->error = 1;
+    const int stop = (nn == 0 || width >= a.max_len) ? 1 : 0;
+    st->stop = stop;
+    st->n_active = stop ? 0 : nn;
+    st->r_rows = stop ? 0 : nn * a.N;
+    st->m_rows = stop ? 0 : nn * a.N * D1;
+    *a.host_flag = stop;
+    __threadfence_system();
+  }
+}
+
+// Copy the K/V rows of the accepted positions (chosen draft, j = 0..nacc) from the step's packed
+// QKV buffer of every decoder layer into the KV cache at positions front_old + j.
+struct KvCopyArgs {
+  const DecState* st; const CopyRec* rec;
+  const float* qkv; long long qkv_layer_stride;      // [Ld][Mmax][3d]
+  float* kcache; float* vcache; long long cache_layer_stride; long long cache_seq_stride;
+  int N, D1, d;
+};
+
+__global__ __launch_bounds__(256) void k_kvcopy(KvCopyArgs a) {
+  const int slot = blockIdx.x, l = blockIdx.y;
+  if (slot >= a.st->n_copy) return;
+  const CopyRec r = a.rec[slot];
+  const float* src = a.qkv + (size_t)l * a.qkv_layer_stride + ((size_t)(slot * a.N + r.best) * a.D1) * 3 * a.d;
+  float* kc = a.kcache + (size_t)l * a.cache_layer_stride + (size_t)r.b * a.cache_seq_stride + (size_t)r.front_old * a.d;
+  float* vc = a.vcache + (size_t)l * a.cache_layer_stride + (size_t)r.b * a.cache_seq_stride + (size_t)r.front_old * a.d;
+  const int per_row = a.d / 4;                    // float4 per K (or V) row
+  const int total = (r.nacc + 1) * per_row;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int j = e / per_row, c = (e % per_row) * 4;
+    const float* p = src + (size_t)j * 3 * a.d;
+    *reinterpret_cast<float4*>(kc + (size_t)j * a.d + c) = *reinterpret_cast<const float4*>(p + a.d + c);
+    *reinterpret_cast<float4*>(vc + (size_t)j * a.d + c) = *reinterpret_cast<const float4*>(p + 2 * a.d + c);
+  }
+}
+
+}  // namespace ttx

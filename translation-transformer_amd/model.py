@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference model protocol over the HIP library.
+
+``NativeTransformer`` offers what the reference's generators call on ``VanillaTransformer``
+(src/model/modules.py:86-138): ``src_pad_token_i``, ``encode_src(src, src_pad_mask)``,
+``decode_tgt(tgt, memory, memory_pad_mask=...)`` and ``model(src, tgt)`` — same argument meaning, same
+tensor shapes/dtypes out — so the reference's own generator classes can drive it unchanged, and it owns
+the ``ttx_session`` the native generators of decoding.py run on.  torch is used for device memory and
+the current stream only; every FLOP happens in libttx_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as N
+
+
+def reference_pe_table(emb: int, max_len: int = 5000) -> torch.Tensor:
+    """The non-persistent ``pe`` buffer of the reference (src/model/embeddings.py:38-45), rebuilt with the
+    same torch ops so the table handed to the library is bit-identical to the one the reference adds."""
+    pe = torch.zeros(max_len, emb)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, emb, 2).float() * (-math.log(10000.0) / emb))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return torch.vstack((torch.zeros(1, emb), pe)).contiguous()
+
+
+def _strip(state: dict) -> dict:
+    if any(k.startswith("model.") for k in state):
+        return {k[len("model."):]: v for k, v in state.items() if k.startswith("model.")}
+    return dict(state)
+
+
+class NativeTransformer:
+    def __init__(self, state_dict: dict, num_heads: int, pad_token_idx: int = 0, device: int | str | torch.device = 0,
+                 max_positions: int = 5000, layer_norm_eps: float = 1e-5):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeTransformer needs an MI355X: the HIP path has no CPU fallback")
+        st = _strip(state_dict)
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        self.device = dev
+        emb = st["src_token_featurizer.embedding.weight"]
+        self.emb_dim = int(emb.shape[1])
+        self.num_heads = int(num_heads)
+        self.src_vocab_size = int(emb.shape[0])
+        self.tgt_vocab_size = int(st["next_token_classifier.weight"].shape[0])
+        self.ff_dim = int(st["transformer.encoder.layers.0.linear1.weight"].shape[0])
+        self.num_enc_layers = 1 + max(int(k.split(".")[3]) for k in st if k.startswith("transformer.encoder.layers."))
+        self.num_dec_layers = 1 + max(int(k.split(".")[3]) for k in st if k.startswith("transformer.decoder.layers."))
+        self.src_pad_token_i = int(pad_token_idx)
+        self.tgt_pad_token_i = int(pad_token_idx)
+        self.cfg = N.Config(self.tgt_vocab_size, self.src_vocab_size, self.emb_dim, self.num_heads, self.ff_dim,
+                            self.num_enc_layers, self.num_dec_layers, self.src_pad_token_i, int(max_positions),
+                            float(layer_norm_eps))
+        host = {k: torch.as_tensor(v).detach().to("cpu", torch.float32).contiguous() for k, v in st.items()}
+        host["positional_encoding.pe"] = reference_pe_table(self.emb_dim, max_positions)
+        arr = (N.Tensor * len(host))()
+        keep = []
+        for i, (k, v) in enumerate(host.items()):
+            name = k.encode()
+            keep.append((name, v))
+            arr[i] = N.Tensor(name, C.cast(v.data_ptr(), C.POINTER(C.c_float)), v.numel())
+        self._lib = N.lib()
+        self._model = C.c_void_p()
+        N.check(self._lib.ttx_model_create(C.byref(self.cfg), arr, len(host), dev.index or 0, C.byref(self._model)))
+        self._session = C.c_void_p()
+        N.check(self._lib.ttx_session_create(self._model, C.byref(self._session)))
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def session(self) -> C.c_void_p:
+        return self._session
+
+    def new_session(self) -> C.c_void_p:
+        s = C.c_void_p()
+        N.check(self._lib.ttx_session_create(self._model, C.byref(s)))
+        return s
+
+    def close(self) -> None:
+        if getattr(self, "_session", None):
+            self._lib.ttx_session_destroy(self._session)
+            self._session = None
+        if getattr(self, "_model", None):
+            self._lib.ttx_model_destroy(self._model)
+            self._model = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _tokens(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(self.device, torch.int64).contiguous()
+
+    # -- B5 ------------------------------------------------------------------------------------
+    def encode_src(self, src: torch.Tensor, src_pad_mask: torch.Tensor | None = None) -> torch.Tensor:
+        """modules.py:110-116.  The mask argument is accepted for signature parity; the library derives
+        it as ``src == pad`` exactly as every reference call site does (speculative_decoding.py:60)."""
+        src = self._tokens(src)
+        B, Ls = src.shape
+        mem = torch.empty((B, Ls, self.emb_dim), dtype=torch.float32, device=self.device)
+        N.check(self._lib.ttx_encode_src(self._session, src.data_ptr(), B, Ls, mem.data_ptr(), self._stream()))
+        return mem
+
+    def decode_tgt(self, tgt: torch.Tensor, memory: torch.Tensor, memory_pad_mask: torch.Tensor,
+                   memory_row: torch.Tensor | None = None) -> torch.Tensor:
+        """modules.py:118-138.  ``memory_row`` (int32 [R], optional) lets R decoder rows share fewer
+        memory rows instead of the reference's repeat_interleave'd copy."""
+        tgt = self._tokens(tgt)
+        R, Lt = tgt.shape
+        memory = memory.to(self.device, torch.float32).contiguous()
+        Rm, Ls, _ = memory.shape
+        pad = memory_pad_mask.to(self.device, torch.uint8).contiguous()
+        row_ptr = None
+        if memory_row is not None:
+            memory_row = memory_row.to(self.device, torch.int32).contiguous()
+            row_ptr = memory_row.data_ptr()
+        logits = torch.empty((R, Lt, self.tgt_vocab_size), dtype=torch.float32, device=self.device)
+        N.check(self._lib.ttx_decode_tgt(self._session, tgt.data_ptr(), R, Lt, memory.data_ptr(), pad.data_ptr(),
+                                         row_ptr, Rm, Ls, logits.data_ptr(), self._stream()))
+        return logits
+
+    def __call__(self, src: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+        """modules.py:86-108."""
+        src, tgt = self._tokens(src), self._tokens(tgt)
+        B, Ls = src.shape
+        Lt = tgt.shape[1]
+        logits = torch.empty((B, Lt, self.tgt_vocab_size), dtype=torch.float32, device=self.device)
+        N.check(self._lib.ttx_forward(self._session, src.data_ptr(), B, Ls, tgt.data_ptr(), Lt, logits.data_ptr(),
+                                      self._stream()))
+        return logits
+
+    forward = __call__
+
+    def make_drafts(self, src: torch.Tensor, draft_len: int, n_drafts: int, min_draft_len: int, max_draft_len: int,
+                    eos_token_idx: int, pad_token_idx: int, replace_token_idx: int) -> torch.Tensor:
+        """src/utils/drafting.py:5-67 on the device."""
+        src = self._tokens(src)
+        B, L = src.shape
+        D = min(max(min_draft_len, draft_len), max_draft_len)
+        out = torch.empty((B, n_drafts, D), dtype=torch.int64, device=self.device)
+        N.check(self._lib.ttx_make_drafts(self._session, src.data_ptr(), B, L, draft_len, n_drafts, min_draft_len,
+                                          max_draft_len, eos_token_idx, pad_token_idx, replace_token_idx,
+                                          out.data_ptr(), self._stream()))
+        return out
