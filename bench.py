@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native greedy-speculative decoding path (BASELINE.json configs[1]):
+reactions/sec at bs=32, draft_len=10, n_drafts=3, max_len=200 on USPTO-MIT-shaped synthetic SMILES.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one batch of 32 reactions through ``generate`` (encoder + the whole verify loop).  Inputs are
+resident in HBM before the timed region; every rank decodes its own shard of the synthetic test set (weak
+scaling, no data-path collective); weights are broadcast once from rank 0 and predictions gathered once at
+the end over RCCL.  Rank 0 prints ONE JSON line.
+
+Weights: there is no checkpoint offline, so a full-size (d=256, 8 heads, FFN 2048, 4+4) model is trained
+on the synthetic task by tools/train_synth.py for a fixed step budget (cached under /tmp for later runs
+on the same box).  That is set-up, outside every timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MATRIX_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0            # same guide: HBM3E 8 TB/s spec
+BASELINE_REACTIONS_PER_S = 47.97  # BASELINE.md §1, bs=32 D=10 N=3 (reference's own run, unstated GPU)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--draft-len", type=int, default=10)
+    ap.add_argument("--n-drafts", type=int, default=3)
+    ap.add_argument("--max-len", type=int, default=200)
+    ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "2500")))
+    ap.add_argument("--cpu-batches", type=int, default=1, help="batches of the workload timed on the host cores")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("TTX_CPU_THREADS", "64"))))
+
+
+def log(*a):
+    if os.environ.get("TTX_BENCH_VERBOSE") == "1":
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def get_weights(train_steps: int, device: str) -> dict:
+    path = os.environ.get("TTX_WEIGHTS") or f"/tmp/ttx_synth_mit_{train_steps}.pt"
+    if os.path.exists(path):
+        return torch.load(path, weights_only=True, map_location="cpu")
+    from tools.train_synth import train
+    sd = train("mit", steps=train_steps, device=device, verbose=os.environ.get("TTX_BENCH_VERBOSE") == "1")
+    try:
+        torch.save(sd, path)
+        extra = os.environ.get("TTX_SAVE_WEIGHTS")
+        if extra:
+            torch.save(sd, extra)
+    except OSError:
+        pass
+    return sd
+
+
+def flops_and_bytes(cfg: dict, stats: dict, B_total_src_tokens: int, n_batches: int) -> dict:
+    """Algorithmic work of the KV-cached algorithm: dense FLOPs of every GEMM launch and
+    HBM bytes (weights once per step / per batch, K/V cache reads and writes)."""
+    d, F, V, Le, Ld = cfg["d"], cfg["F"], cfg["V"], cfg["Le"], cfg["Ld"]
+    pos = stats["verified_positions"]
+    dec_dense_per_pos = Ld * (12 * d * d + 4 * d * F) + 2 * d * V          # qkv+o+cq+co = 6 d^2 MAC -> 12 d^2 FLOP
+    enc_dense_per_tok = Le * (8 * d * d + 4 * d * F)
+    cross_kv_per_tok = Ld * 4 * d * d
+    gemm_flops = pos * dec_dense_per_pos + B_total_src_tokens * (enc_dense_per_tok + cross_kv_per_tok)
+    P_e = 4 * d * d + 4 * d + 2 * d * F + F + d + 4 * d
+    P_d = 2 * (4 * d * d + 4 * d) + 2 * d * F + F + d + 6 * d
+    W_enc = 4 * (Le * P_e + 2 * d + V * d)
+    W_dec = 4 * (Ld * P_d + 2 * d + d * V + V)
+    steps = stats["model_calls"]
+    kv_read = (stats["kv_prefix_positions"] + stats["src_positions"]) * 2 * d * 4 * Ld
+    kv_write = stats["produced_tokens"] * 2 * d * 4 * Ld
+    bytes_total = n_batches * W_enc + steps * W_dec + kv_read + kv_write
+    return {"gemm_flops": float(gemm_flops), "bytes": float(bytes_total)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl")   # RCCL over xGMI
+
+    import translation_transformer_amd as tta
+    from tools.synth import SynthReactions, batches, PAD, BOS, EOS, C_TOK, V
+
+    # ---- weights: rank 0 trains/loads, one RCCL broadcast of the packed fp32 blob
+    names = shapes = None
+    if rank == 0:
+        sd = get_weights(a.train_steps, dev)
+        names = list(sd.keys())
+        shapes = [tuple(sd[k].shape) for k in names]
+        flat = torch.cat([sd[k].reshape(-1).float() for k in names]).to(dev)
+    if world > 1:
+        meta = [names, shapes]
+        dist.broadcast_object_list(meta, src=0)
+        names, shapes = meta
+        n = sum(int(np.prod(s)) for s in shapes)
+        if rank != 0:
+            flat = torch.empty(n, dtype=torch.float32, device=dev)
+        dist.broadcast(flat, src=0)
+    host = flat.cpu()
+    sd, off = {}, 0
+    for k, s in zip(names, shapes):
+        n = int(np.prod(s))
+        sd[k] = host[off:off + n].reshape(s)
+        off += n
+    model = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=PAD, device=local_rank)
+    cfg = {"d": model.emb_dim, "F": model.ff_dim, "V": model.tgt_vocab_size, "Le": model.num_enc_layers,
+           "Ld": model.num_dec_layers}
+
+    # ---- data: every rank takes its own contiguous shard of the synthetic test set (seed 123456)
+    per_rank = (a.steps + a.warmup) * a.batch_size
+    src_all, _ = SynthReactions(123456, "mit").dataset(per_rank * world)
+    mine = src_all[rank * per_rank:(rank + 1) * per_rank]
+    dev_batches = [torch.from_numpy(b).to(dev) for b in batches(mine, a.batch_size)]
+    warm, timed = dev_batches[:a.warmup], dev_batches[a.warmup:]
+
+    def make_gen(m):
+        return tta.TranslationInferenceGreedySpeculative(m, a.max_len, a.draft_len, a.n_drafts, PAD, BOS, EOS, C_TOK)
+
+    gen = make_gen(model)
+    log("model ready; warmup")
+    for b in warm:
+        gen.generate(b)
+    log("warmup done", gen.model_calls_num, "calls")
+    gen = make_gen(model)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [gen.generate(b) for b in timed]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log("timed region done", elapsed, "s", gen.model_calls_num, "calls")
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- prediction gather: one collective at the end, int16 tokens
+    preds = torch.cat([o[:, 0, :] for o in outs]).to(torch.int16)
+    if dist:
+        gathered = [torch.empty_like(preds) for _ in range(world)] if rank == 0 else None
+        dist.gather(preds, gathered, dst=0)
+    n_reactions = world * len(timed) * a.batch_size
+    stats = dict(gen.stats_total)
+    stats["model_calls"] = gen.model_calls_num
+    finished = int((preds == EOS).any(dim=1).sum())
+
+    line = {
+        "metric": "reactions/sec (SMILES decoded), greedy speculative", "value": n_reactions / elapsed,
+        "unit": "reactions/s", "n_gpus": world, "steps": len(timed), "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / max(1, len(timed)), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": (n_reactions / elapsed) / BASELINE_REACTIONS_PER_S, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"USPTO-MIT-shaped synthetic SMILES, greedy speculative draft_len={a.draft_len} "
+                               f"n_drafts={a.n_drafts} bs={a.batch_size} max_len={a.max_len}, d=256 8h FFN2048 4+4 fp32, "
+                               f"weights trained {a.train_steps} steps on the synthetic task",
+                   "reactions": n_reactions, "parallelism": f"test-set shards x{world}, no per-step collective"},
+        "model_calls": stats["model_calls"], "rows_finished_rank0": finished, "rows_rank0": int(preds.shape[0]),
+        "accepted_per_step_per_row": stats["accepted_tokens"] / max(1, stats["produced_tokens"] - stats["accepted_tokens"]),
+        "device_ms_encode_rank0": stats["encode_ms"], "device_ms_decode_rank0": stats["decode_ms"],
+    }
+
+    if rank == 0:
+        work = flops_and_bytes(cfg, stats, stats["src_tokens_padded"], len(timed))
+        line["hbm_algorithmic"] = {"bytes_per_reaction": work["bytes"] / (len(timed) * a.batch_size),
+                                   "achieved_GBs": work["bytes"] / elapsed / 1e9,
+                                   "frac_of_peak": work["bytes"] / elapsed / 1e9 / PEAK_HBM_GBS}
+        if not a.no_profile:
+            # dominant kernel = k_gemm_tn (fp32 MFMA GEMM): HIP events on the launch stream around every launch,
+            # same batches, same process, right after the timed region
+            os.environ["TTX_PROFILE_GEMM"] = "1"
+            pm = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=PAD, device=local_rank)
+            os.environ.pop("TTX_PROFILE_GEMM")
+            pg = make_gen(pm)
+            import ctypes as C
+            gemm_ms, launches = 0.0, 0
+            for b in timed:
+                pg.generate(b)
+                ms, n = C.c_double(), C.c_int64()
+                pm._lib.ttx_last_kernel_profile(pm.session, C.byref(ms), C.byref(n))
+                gemm_ms += ms.value
+                launches += n.value
+            pstats = dict(pg.stats_total)
+            pstats["model_calls"] = pg.model_calls_num
+            pw = flops_and_bytes(cfg, pstats, pstats["src_tokens_padded"], len(timed))
+            ach = pw["gemm_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            line["roofline"] = {"kernel": "k_gemm_tn (fp32 v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach,
+                                "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
+                                "traffic": None, "launches": launches, "avg_launch_us": 1e3 * gemm_ms / max(1, launches),
+                                "flops_per_launch": pw["gemm_flops"] / max(1, launches),
+                                "gemm_share_of_decode_time": gemm_ms / max(1e-9, pstats["encode_ms"] + pstats["decode_ms"])}
+            pm.close()
+            log("profile pass done")
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle.model import OracleTransformer, config_from_state
+            from oracle.decoding import GreedySpeculativeOracle
+            cores = usable_cores()
+            torch.set_num_threads(cores)
+            log("cpu baseline on", cores, "threads")
+            om = OracleTransformer(config_from_state(sd, 8, PAD), sd)
+            og = GreedySpeculativeOracle(om, a.max_len, a.draft_len, a.n_drafts, PAD, BOS, EOS, C_TOK)
+            sample = timed[:a.cpu_batches]
+            with torch.inference_mode():
+                t1 = time.perf_counter()
+                cpu_out = [og.generate(b.cpu()) for b in sample]
+                cpu_s = time.perf_counter() - t1
+            same = sum(int(torch.equal(c[:, 0], o[:, 0].cpu())) for c, o in zip(cpu_out, outs))
+            rows_same = sum(int((c[:, 0] == o[:, 0].cpu()).all(dim=1).sum()) for c, o in zip(cpu_out, outs))
+            n_cpu = len(sample) * a.batch_size
+            line["cpu_baseline"] = {"value": n_cpu / cpu_s, "unit": "reactions/s", "cores": cores, "kind": "port",
+                                    "sample": f"first {len(sample)} timed batch(es) = {n_cpu} reactions of the same workload, "
+                                              f"oracle/ (full-prefix recompute like the reference), torch {torch.__version__} fp32",
+                                    "seconds": cpu_s, "model_calls": og.model_calls_num}
+            line["parity"] = {"rows_token_identical_to_oracle": rows_same, "rows_checked": n_cpu,
+                              "batches_identical": same}
+        print(json.dumps(line))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
