@@ -264,6 +264,7 @@ struct ttx_session {
   size_t attn_lds_limit = 0;
   // profiling of the GEMM launches (bench.py roofline)
   bool profile = false;
+  bool gemm_v1 = false, attn_v1 = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double prof_ms = 0;
@@ -305,6 +306,8 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   HIP_TRY(hipEventCreate(&s->ev_c));
   const char* pf = getenv("TTX_PROFILE_GEMM");
   s->profile = pf && pf[0] == '1';
+  s->gemm_v1 = getenv("TTX_GEMM_V1") != nullptr;
+  s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   *out = s;
   return TTX_OK;
 }
@@ -359,6 +362,14 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
   if (Mmax <= 32) {
     dim3 grid(cdiv(N, 128), cdiv(Mmax, 32), S);
     hipLaunchKernelGGL((k_gemm_tn<1, 4>), grid, dim3(256), 0, st, a);
+  } else if ((a.k_per_split == 64 || a.k_per_split == 128 || a.k_per_split % 256 == 0) && !s->gemm_v1) {
+    dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
+    switch (a.k_per_split) {
+      case 64: hipLaunchKernelGGL((k_gemm2<1>), grid, dim3(256), 0, st, a); break;
+      case 128: hipLaunchKernelGGL((k_gemm2<2>), grid, dim3(256), 0, st, a); break;
+      case 256: hipLaunchKernelGGL((k_gemm2<4>), grid, dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((k_gemm2<0>), grid, dim3(256), 0, st, a); break;
+    }
   } else {
     dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
     hipLaunchKernelGGL((k_gemm_tn<2, 2>), grid, dim3(256), 0, st, a);
@@ -389,15 +400,40 @@ static int launch_finish(ttx_session* s, hipStream_t st, const float* slabs, int
   return TTX_OK;
 }
 
+static constexpr size_t kAttn2LdsLimit = 150 * 1024;
+
+// `groups` = sources / decoder rows / running-sequence slots; `q_per_group` = query rows of one group
+// (Ls, Lt, or N*(D+1)); for the step modes `D1`/`N` shape the draft tiles.  Uses the MFMA kernel
+// (k_attn2) whenever its LDS score/K/V images fit, else the streaming wave-per-row kernel (k_attn).
 template <int MODE>
-static int launch_attn(ttx_session* s, hipStream_t st, const AttnArgs& a, dim3 grid, int max_keys) {
-  const size_t lds = attn_lds_bytes(max_keys);
-  if (lds > 160 * 1024 - 512) return fail(TTX_ERR_INVALID, "sequence too long for the attention kernel's LDS score buffer");
-  if (lds > 64 * 1024) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+static int launch_attn(ttx_session* s, hipStream_t st, const AttnArgs& a, int groups, int H, int q_per_group, int max_keys,
+                       int N = 1, int D1 = 1) {
+  if (groups <= 0 || q_per_group <= 0) return TTX_OK;
+  constexpr bool step = (MODE == ATT_STEP_SELF || MODE == ATT_STEP_CROSS);
+  const int keys2 = (MODE == ATT_STEP_SELF) ? max_keys + std::max(A2_QT, D1) : max_keys;
+  const size_t lds2 = attn2_lds_bytes(keys2);
+  if (lds2 <= kAttn2LdsLimit && !s->attn_v1) {
+    int tiles;
+    if (step) tiles = (D1 <= A2_QT) ? cdiv(N, A2_QT / D1) : N * cdiv(D1, A2_QT);
+    else tiles = cdiv(q_per_group, A2_QT);
+    static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+    if (lds2 > 64 * 1024 && !attr_set[MODE]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn2<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kAttn2LdsLimit));
+      attr_set[MODE] = true;
+    }
+    hipLaunchKernelGGL((k_attn2<MODE>), dim3(groups, H, tiles), dim3(256), lds2, st, a);
+    HIP_TRY(hipGetLastError());
+    return TTX_OK;
   }
-  if (grid.x == 0 || grid.y == 0 || grid.z == 0) return TTX_OK;
-  hipLaunchKernelGGL((k_attn<MODE>), grid, dim3(64), lds, st, a);
+  const int keys1 = (MODE == ATT_STEP_SELF) ? max_keys + D1 : max_keys;
+  const size_t lds = attn_lds_bytes(keys1);
+  if (lds > kAttn2LdsLimit) return fail(TTX_ERR_INVALID, "sequence too long for the attention kernels' LDS score buffer");
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int rows = step ? groups * N : groups;
+  const int qn = step ? D1 : q_per_group;
+  hipLaunchKernelGGL((k_attn<MODE>), dim3(rows, H, cdiv(qn, ATT_MAXQ)), dim3(64), lds, st, a);
   HIP_TRY(hipGetLastError());
   return TTX_OK;
 }
@@ -453,7 +489,7 @@ static int run_encoder(ttx_session* s, hipStream_t st, const int* tok, const uin
     AttnArgs a{};
     a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d;
     a.scale = 1.0f / sqrtf((float)ATT_DH); a.L = Ls; a.tok = tok; a.pad = c.pad_token;
-    TTX_TRY(launch_attn<ATT_ENC>(s, st, a, dim3(B, H, cdiv(Ls, ATT_MAXQ)), Ls));
+    TTX_TRY(launch_attn<ATT_ENC>(s, st, a, B, H, Ls, Ls));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
                     nullptr, x1, nullptr, M));
     TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, nullptr, M, F, d, true, 0, 0));
@@ -512,7 +548,7 @@ static int run_decoder_full(ttx_session* s, hipStream_t st, const int* tok, int 
     AttnArgs a{};
     a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d; a.scale = scale;
     a.L = Lt; a.tok = tok; a.pad = c.pad_token;
-    TTX_TRY(launch_attn<ATT_FULL_SELF>(s, st, a, dim3(R, H, cdiv(Lt, ATT_MAXQ)), Lt));
+    TTX_TRY(launch_attn<ATT_FULL_SELF>(s, st, a, R, H, Lt, Lt));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
                     nullptr, x1, nullptr, M));
     // cross attention: Q from the decoder stream, K/V re-projected from `memory` (as the reference does per call)
@@ -522,7 +558,7 @@ static int run_decoder_full(ttx_session* s, hipStream_t st, const int* tok, int 
     AttnArgs ca{};
     ca.q = q2; ca.ldq = d; ca.k = ckv; ca.v = ckv + d; ca.ldkv = 2 * d; ca.out = ao; ca.d = d; ca.scale = scale;
     ca.L = Lt; ca.Lk = Ls; ca.key_pad = mem_pad; ca.mem_row = mem_row;
-    TTX_TRY(launch_attn<ATT_FULL_CROSS>(s, st, ca, dim3(R, H, cdiv(Lt, ATT_MAXQ)), Ls));
+    TTX_TRY(launch_attn<ATT_FULL_CROSS>(s, st, ca, R, H, Lt, Ls));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
                     nullptr, x2, nullptr, M));
     TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, nullptr, M, F, d, true, 0, 0));
@@ -628,7 +664,6 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k) {
   const long long qkv_layer = (long long)Mmax * 3 * d;
   const long long cache_seq = (long long)k.Lc * d;
   const long long cache_layer = (long long)k.B * cache_seq;
-  const int qtiles = cdiv(D1, ATT_MAXQ);
 
   EmbedArgs e{};
   e.table = m->p(m->tgt_emb); e.pe = m->p(m->pe); e.X = x; e.d = d;
@@ -647,7 +682,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k) {
     a.tok = s->gen.as<int>(); a.pad = c.pad_token; a.st = dst; a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>();
     a.kcache = s->kcache.as<float>() + (size_t)l * cache_layer; a.vcache = s->vcache.as<float>() + (size_t)l * cache_layer;
     a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D1 = D1;
-    TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, dim3(Rmax, H, qtiles), k.Lc));
+    TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, k.B, H, k.N * D1, k.max_len, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
                     nullptr, x1, m_ptr, Mmax));
     TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, m_ptr, Mmax, d, d, false, 0, 0));
@@ -655,7 +690,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k) {
     ca.q = q2; ca.ldq = d; ca.k = s->memkv.as<float>() + (size_t)l * 2 * d; ca.v = ca.k + d; ca.ldkv = Ld * 2 * d;
     ca.out = ao; ca.d = d; ca.scale = scale; ca.Lk = k.Ls; ca.key_pad = s->src_valid.as<uint8_t>();
     ca.st = dst; ca.act_idx = s->act_idx.as<int>(); ca.front = s->front.as<int>(); ca.N = k.N; ca.D1 = D1;
-    TTX_TRY(launch_attn<ATT_STEP_CROSS>(s, st, ca, dim3(Rmax, H, qtiles), k.Ls));
+    TTX_TRY(launch_attn<ATT_STEP_CROSS>(s, st, ca, k.B, H, k.N * D1, k.Ls, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
                     nullptr, x2, m_ptr, Mmax));
     TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, m_ptr, Mmax, F, d, true, 0, 0));

@@ -121,16 +121,172 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_tn(GemmArgs a) {
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)
   float* Y = a.Y + (a.raw ? (size_t)blockIdx.z * a.slab_stride : 0);
   const int col = n0 + wn * 32 + r;
+  // all values are finished before the first (predicated) store: a pending load inside the store
+  // branches would make the compiler drain vmcnt — and with it the previous store — sixteen times
+  const float bv = (!a.raw && a.bias) ? a.bias[min(col, a.N - 1)] : 0.f;
+  const float lo = a.relu ? 0.f : -INFINITY;
+  float val[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) val[v] = fmaxf(acc[v] + bv, lo);
   if (col < a.N) {
-    const float bv = (!a.raw && a.bias) ? a.bias[col] : 0.f;
+    float* yp = Y + (size_t)(m0 + wm * 32 + 4 * h) * a.ldy + col;
+    const int rows_left = M - (m0 + wm * 32 + 4 * h);
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-      const int row = m0 + wm * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-      if (row < M) {
-        float val = acc[v] + bv;
-        if (a.relu) val = fmaxf(val, 0.f);
-        Y[(size_t)row * a.ldy + col] = val;
-      }
+      const int dr = (v & 3) + 8 * (v >> 2);
+      if (dr < rows_left) yp[(size_t)dr * a.ldy] = val[v];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM v2 for the decode-step shapes (M <= ~1000 rows, K = 256 per workgroup): every launch is a few
+// hundred workgroups at most, so one workgroup's time is load latency, not bandwidth.  Each thread
+// therefore keeps a ring of four 64-deep K tiles in flight in registers (all of K = 256 is requested
+// from L2/Infinity Cache before the first MFMA), LDS is double-buffered so one barrier per tile
+// suffices, and the 64x64 output tile is four 32x32 fp32-MFMA accumulators, one per wave.
+struct G2Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
+struct G2Ptrs { const float* x0; const float* x1; const float* x2; const float* x3;
+                const float* w0; const float* w1; const float* w2; const float* w3; };
+
+// Unconditional loads (row/column indices are clamped by the caller): rows >= M and columns >= N only
+// ever feed accumulator rows/columns that the epilogue does not store, and branch-free loads let the
+// compiler keep counted vmcnt waits instead of draining everything.
+__device__ __forceinline__ G2Frag g2_load(const G2Ptrs& p, int koff) {
+  G2Frag f;
+  f.a0 = *reinterpret_cast<const float4*>(p.x0 + koff);
+  f.a1 = *reinterpret_cast<const float4*>(p.x1 + koff);
+  f.a2 = *reinterpret_cast<const float4*>(p.x2 + koff);
+  f.a3 = *reinterpret_cast<const float4*>(p.x3 + koff);
+  f.b0 = *reinterpret_cast<const float4*>(p.w0 + koff);
+  f.b1 = *reinterpret_cast<const float4*>(p.w1 + koff);
+  f.b2 = *reinterpret_cast<const float4*>(p.w2 + koff);
+  f.b3 = *reinterpret_cast<const float4*>(p.w3 + koff);
+  return f;
+}
+
+template <int LDT>
+__device__ __forceinline__ void g2_store(const G2Frag& f, float* as, float* bs, int lr, int lc) {
+  *reinterpret_cast<float4*>(&as[(lr) * LDT + lc]) = f.a0;
+  *reinterpret_cast<float4*>(&as[(16 + lr) * LDT + lc]) = f.a1;
+  *reinterpret_cast<float4*>(&as[(32 + lr) * LDT + lc]) = f.a2;
+  *reinterpret_cast<float4*>(&as[(48 + lr) * LDT + lc]) = f.a3;
+  *reinterpret_cast<float4*>(&bs[(lr) * LDT + lc]) = f.b0;
+  *reinterpret_cast<float4*>(&bs[(16 + lr) * LDT + lc]) = f.b1;
+  *reinterpret_cast<float4*>(&bs[(32 + lr) * LDT + lc]) = f.b2;
+  *reinterpret_cast<float4*>(&bs[(48 + lr) * LDT + lc]) = f.b3;
+}
+
+template <int BK, int LDT>
+__device__ __forceinline__ void g2_mma(f32x16& acc, const float* ap, const float* bp) {
+#pragma unroll
+  for (int kk = 0; kk < BK; kk += 8) {
+    const float4 av = *reinterpret_cast<const float4*>(ap + kk);
+    const float4 bv = *reinterpret_cast<const float4*>(bp + kk);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+  }
+}
+
+// NT = number of 64-deep K tiles per workgroup when it is 1, 2 or 4 (straight-line code, every tile
+// requested up front); NT = 0: any multiple of 4 tiles, ring slots refilled as they drain.
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
+  constexpr int BM = 64, BN = 64, BK = 64, LDT = BK + 4, RING = 4;
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
+
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (m0 >= M) return;
+  const int kbeg = blockIdx.z * a.k_per_split;
+  const int kend = min(a.K, kbeg + a.k_per_split);
+  const int ntiles = (kend - kbeg) / BK;
+
+  const int t = threadIdx.x;
+  const int lr = t >> 4, lc = (t & 15) * 4;      // 16 float4 per 64-float row, 16 rows per pass
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  G2Ptrs p;
+  {
+    const int r0 = m0 + lr, c0 = n0 + lr;
+    const float* xb = a.X + kbeg + lc;
+    const float* wb = a.W + kbeg + lc;
+    p.x0 = xb + (size_t)min(r0, M - 1) * a.ldx;
+    p.x1 = xb + (size_t)min(r0 + 16, M - 1) * a.ldx;
+    p.x2 = xb + (size_t)min(r0 + 32, M - 1) * a.ldx;
+    p.x3 = xb + (size_t)min(r0 + 48, M - 1) * a.ldx;
+    p.w0 = wb + (size_t)min(c0, a.N - 1) * a.ldw;
+    p.w1 = wb + (size_t)min(c0 + 16, a.N - 1) * a.ldw;
+    p.w2 = wb + (size_t)min(c0 + 32, a.N - 1) * a.ldw;
+    p.w3 = wb + (size_t)min(c0 + 48, a.N - 1) * a.ldw;
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int aoff = (wm * 32 + r) * LDT + 4 * h, boff = (wn * 32 + r) * LDT + 4 * h;
+
+  if constexpr (NT == 1) {
+    const G2Frag f0 = g2_load(p, 0);
+    g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
+    __syncthreads();
+    g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
+  } else if constexpr (NT == 2) {
+    const G2Frag f0 = g2_load(p, 0);
+    const G2Frag f1 = g2_load(p, BK);
+    g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
+    g2_store<LDT>(f1, As[1], Bs[1], lr, lc);
+    __syncthreads();
+    g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
+    g2_mma<BK, LDT>(acc, As[1] + aoff, Bs[1] + boff);
+  } else {
+    // ring of four register tiles, two LDS buffers; slot indices are compile-time (no register moves:
+    // moving a pending load's destination would force a wait on it)
+    G2Frag f0 = g2_load(p, 0);
+    G2Frag f1 = g2_load(p, BK);
+    G2Frag f2 = g2_load(p, 2 * BK);
+    G2Frag f3 = g2_load(p, 3 * BK);
+    const int last = ntiles - 1;
+    for (int base = 0; base < ntiles; base += RING) {
+      g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
+      if constexpr (NT == 0) f0 = g2_load(p, min(base + RING, last) * BK);      // clamped: branch-free refill
+      __syncthreads();
+      g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
+      g2_store<LDT>(f1, As[1], Bs[1], lr, lc);
+      if constexpr (NT == 0) f1 = g2_load(p, min(base + RING + 1, last) * BK);
+      __syncthreads();
+      g2_mma<BK, LDT>(acc, As[1] + aoff, Bs[1] + boff);
+      g2_store<LDT>(f2, As[0], Bs[0], lr, lc);
+      if constexpr (NT == 0) f2 = g2_load(p, min(base + RING + 2, last) * BK);
+      __syncthreads();
+      g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
+      g2_store<LDT>(f3, As[1], Bs[1], lr, lc);
+      if constexpr (NT == 0) f3 = g2_load(p, min(base + RING + 3, last) * BK);
+      __syncthreads();
+      g2_mma<BK, LDT>(acc, As[1] + aoff, Bs[1] + boff);
+    }
+  }
+
+  float* Y = a.Y + (a.raw ? (size_t)blockIdx.z * a.slab_stride : 0);
+  const int col = n0 + wn * 32 + r;
+  // all values are finished before the first (predicated) store: a pending load inside the store
+  // branches would make the compiler drain vmcnt — and with it the previous store — sixteen times
+  const float bv = (!a.raw && a.bias) ? a.bias[min(col, a.N - 1)] : 0.f;
+  const float lo = a.relu ? 0.f : -INFINITY;
+  float val[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) val[v] = fmaxf(acc[v] + bv, lo);
+  if (col < a.N) {
+    float* yp = Y + (size_t)(m0 + wm * 32 + 4 * h) * a.ldy + col;
+    const int rows_left = M - (m0 + wm * 32 + 4 * h);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int dr = (v & 3) + 8 * (v >> 2);
+      if (dr < rows_left) yp[(size_t)dr * a.ldy] = val[v];
     }
   }
 }
@@ -390,6 +546,279 @@ __global__ __launch_bounds__(64) void k_attn(AttnArgs a) {
               [=](int key) { return kv[key] != 0; },
               (const float*)nullptr, (const float*)nullptr, 0, 0, 0, never,
               a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention v2 (the fast path; k_attn above stays as the long-sequence fallback).
+// One 256-thread workgroup per (group, head, tile of <= 32 queries) where a group is one source /
+// decoder row / running sequence, so the N drafts of a sequence share one pass over the cached prefix
+// and over the encoder memory.  K and V of every visible key are staged in LDS by coalesced 128-B row
+// loads issued back to back (one latency, not one per key chunk); S = Q·Kᵀ and O = P·V run on the fp32
+// MFMA (32x32x2), key tiles / key ranges split over the 4 waves; softmax by wavefront shuffles.
+constexpr int A2_QT = 32;                  // queries per tile
+constexpr int A2_LDQ = ATT_DH + 4;         // LDS row stride of Q and K rows (conflict-free ds_read_b128)
+
+__host__ __device__ inline int a2_nkp(int nk) { return (nk + 31) & ~31; }
+__host__ __device__ inline size_t attn2_lds_bytes(int max_keys) {
+  const size_t nkp = a2_nkp(max_keys);
+  return sizeof(float) * ((size_t)A2_QT * A2_LDQ + nkp * A2_LDQ + nkp * ATT_DH + (size_t)A2_QT * (nkp + 4) + A2_QT +
+                          (size_t)4 * A2_QT * 33) +
+         sizeof(int) * (nkp + A2_QT);
+}
+
+// Visibility is decided from one int per key and one per query, computed once while staging:
+//   key flag  < 0        masked (PAD key / padding row)
+//   key flag == A2_ALL   visible to every query (cached prefix, encoder memory)
+//   otherwise (group << 16 | position): visible to queries of the same group at position >= key position
+constexpr int A2_ALL = 0x7fffffff;
+__device__ __forceinline__ bool a2_visible(int qf, int kf) {
+  return kf >= 0 && (kf == A2_ALL || ((kf >> 16) == (qf >> 16) && (kf & 0xffff) <= (qf & 0xffff)));
+}
+
+// keyptr(key, kp, vp): branch-free K/V row pointers of key (0 <= key < nk); keyflag(key), qflag(qi): see above.
+template <class KeyPtr, class KeyFlag, class QFlag>
+__device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq, int nq, int nk, KeyPtr keyptr, KeyFlag keyflag,
+                                           QFlag qflag, float* __restrict__ out, int ldo, float scale, float* lds) {
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int nkp = a2_nkp(nk);
+  const int lds_s = nkp + 4;
+  float* Qs = lds;                                   // [32][36]
+  float* Ks = Qs + A2_QT * A2_LDQ;                   // [nkp][36]
+  float* Vs = Ks + (size_t)nkp * A2_LDQ;             // [nkp][32]
+  float* S = Vs + (size_t)nkp * ATT_DH;              // [32][nkp+4]
+  float* inv = S + (size_t)A2_QT * lds_s;            // [32]
+  float* Op = inv + A2_QT;                           // [4 waves][32][33] partial outputs
+  int* kfl = reinterpret_cast<int*>(Op + 4 * A2_QT * 33);   // [nkp]
+  int* qfl = kfl + nkp;                              // [32]
+
+  // ---- flags first (their token loads overlap the K/V traffic below)
+  for (int key = t; key < nkp; key += 256) kfl[key] = (key < nk) ? keyflag(key) : -1;
+  if (t < A2_QT) qfl[t] = qflag(t);
+
+  // ---- stage Q, K, V: a row is 32 floats = 8 lanes x float4.  Loads are unconditional (indices are
+  // clamped; rows past nq / nk are masked through the flags), so every pass's requests go out back to
+  // back instead of one drained pass at a time.
+  const int lr = t >> 3, lc = (t & 7) * 4;
+  const float4 qv = *reinterpret_cast<const float4*>(q + (size_t)min(lr, nq - 1) * ldq + lc);
+  constexpr int A2_U = 8;                            // passes (of 32 keys) requested before the first LDS write
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  for (int k0 = 0; k0 < nkp; k0 += 32 * A2_U) {
+    f32x4 kv[A2_U], vv[A2_U];
+#pragma unroll
+    for (int u = 0; u < A2_U; ++u) {
+      const float* kp;
+      const float* vp;
+      keyptr(min(k0 + u * 32 + lr, nk - 1), kp, vp);
+      kv[u] = *reinterpret_cast<const f32x4*>(kp + lc);
+      vv[u] = *reinterpret_cast<const f32x4*>(vp + lc);
+    }
+    // every request is in flight before the first value is consumed: the empty asm reads all sixteen
+    // registers, so the scheduler cannot sink a load down to its LDS write
+    asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(kv[4]), "+v"(kv[5]), "+v"(kv[6]), "+v"(kv[7]),
+                      "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]));
+#pragma unroll
+    for (int u = 0; u < A2_U; ++u) {
+      const int key = k0 + u * 32 + lr;
+      if (k0 + u * 32 < nkp) {
+        *reinterpret_cast<f32x4*>(&Ks[(size_t)key * A2_LDQ + lc]) = kv[u];
+        *reinterpret_cast<f32x4*>(&Vs[(size_t)key * ATT_DH + lc]) = vv[u];
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(&Qs[lr * A2_LDQ + lc]) = qv;
+  __syncthreads();
+
+  // ---- S = scale * Q Kᵀ with masking; wave w takes key tiles w, w+4, ...
+  for (int kt = wave; kt * 32 < nkp; kt += 4) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* ap = &Qs[r * A2_LDQ + 4 * h];
+    const float* bp = &Ks[(size_t)(kt * 32 + r) * A2_LDQ + 4 * h];
+#pragma unroll
+    for (int kk = 0; kk < ATT_DH; kk += 8) {
+      const float4 av = *reinterpret_cast<const float4*>(ap + kk);
+      const float4 bv = *reinterpret_cast<const float4*>(bp + kk);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    const int key = kt * 32 + r;
+    const int kf = kfl[key];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int qi = (v & 3) + 8 * (v >> 2) + 4 * h;
+      const bool ok = (qi < nq) && a2_visible(qfl[qi], kf);
+      S[(size_t)qi * lds_s + key] = ok ? acc[v] * scale : -INFINITY;
+    }
+  }
+  __syncthreads();
+
+  // ---- softmax: wave w owns queries 8w..8w+7
+  for (int qi = wave * 8; qi < wave * 8 + 8; ++qi) {
+    float* row = S + (size_t)qi * lds_s;
+    float m = -INFINITY;
+    for (int key = lane; key < nkp; key += 64) m = fmaxf(m, row[key]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int key = lane; key < nkp; key += 64) {
+      const float s = row[key];
+      const float p = (s == -INFINITY) ? 0.f : expf(s - m);
+      row[key] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) inv[qi] = sum > 0.f ? 1.0f / sum : 0.f;
+  }
+  __syncthreads();
+
+  // ---- O = P V: wave w takes keys [w*nkp/4, (w+1)*nkp/4)
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int kq = nkp / 4;
+    const float* prow = S + (size_t)r * lds_s + 4 * h;
+    for (int kb = wave * kq; kb < (wave + 1) * kq; kb += 8) {
+      const float4 pv = *reinterpret_cast<const float4*>(prow + kb);
+      const float* vb = Vs + (size_t)(kb + 4 * h) * ATT_DH + r;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.x, vb[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.y, vb[ATT_DH], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.z, vb[2 * ATT_DH], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.w, vb[3 * ATT_DH], acc, 0, 0, 0);
+    }
+    float* part = Op + (size_t)wave * (A2_QT * 33);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int qi = (v & 3) + 8 * (v >> 2) + 4 * h;
+      part[qi * 33 + r] = acc[v];
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < A2_QT * ATT_DH; e += 256) {
+    const int qi = e >> 5, c = e & 31;
+    const float o = Op[qi * 33 + c] + Op[A2_QT * 33 + qi * 33 + c] + Op[2 * A2_QT * 33 + qi * 33 + c] +
+                    Op[3 * A2_QT * 33 + qi * 33 + c];
+    if (qi < nq) out[(size_t)qi * ldo + c] = o * inv[qi];
+  }
+}
+
+// amdgpu_waves_per_eu(1, 2): the LDS images allow at most two workgroups per CU, so let the compiler keep the
+// staging loads in registers (with the default occupancy target it spills them to scratch to stay under 64 VGPRs)
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_attn2(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int hd = blockIdx.y * ATT_DH;
+  const int tile = blockIdx.z;
+  auto q_any = [](int) { return 0; };
+
+  if constexpr (MODE == ATT_ENC || MODE == ATT_FULL_CROSS) {
+    const int g = blockIdx.x;
+    const int q0 = tile * A2_QT;
+    const int nq = min(A2_QT, a.L - q0);
+    if (nq <= 0) return;
+    const size_t row0 = (size_t)g * a.L;
+    if constexpr (MODE == ATT_ENC) {
+      const int* tk = a.tok + row0;
+      const int pad = a.pad;
+      const float* kb = a.k + row0 * a.ldkv + hd;
+      const float* vb = a.v + row0 * a.ldkv + hd;
+      const int ld = a.ldkv;
+      attn2_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, a.L,
+                 [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
+                 [=](int key) { return tk[key] != pad ? A2_ALL : -1; }, q_any,
+                 a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+    } else {
+      const int mr = a.mem_row ? a.mem_row[g] : g;
+      const size_t mrow0 = (size_t)mr * a.Lk;
+      const uint8_t* kpad = a.key_pad + mrow0;
+      const float* kb = a.k + mrow0 * a.ldkv + hd;
+      const float* vb = a.v + mrow0 * a.ldkv + hd;
+      const int ld = a.ldkv;
+      attn2_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, a.Lk,
+                 [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
+                 [=](int key) { return kpad[key] == 0 ? A2_ALL : -1; }, q_any,
+                 a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+    }
+  } else if constexpr (MODE == ATT_FULL_SELF) {
+    const int g = blockIdx.x;
+    const int q0 = tile * A2_QT;
+    const int nq = min(A2_QT, a.L - q0);
+    if (nq <= 0) return;
+    const size_t row0 = (size_t)g * a.L;
+    const int* tk = a.tok + row0;
+    const int pad = a.pad;
+    const float* kb = a.k + row0 * a.ldkv + hd;
+    const float* vb = a.v + row0 * a.ldkv + hd;
+    const int ld = a.ldkv;
+    attn2_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, min(a.L, q0 + nq),
+               [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
+               [=](int key) { return tk[key] != pad ? key : -1; },       // group 0, position = key
+               [=](int qi) { return q0 + qi; },
+               a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+  } else {
+    // step modes: group = running sequence (slot); a tile holds whole drafts when D+1 <= 32
+    const int slot = blockIdx.x;
+    if (slot >= a.st->n_active) return;
+    const int D1 = a.D1, N = a.N;
+    int n0, nd, j0, nq;
+    if (D1 <= A2_QT) {
+      const int dpt = A2_QT / D1;
+      n0 = tile * dpt;
+      nd = min(dpt, N - n0);
+      j0 = 0;
+      nq = nd * D1;
+    } else {
+      const int tpd = (D1 + A2_QT - 1) / A2_QT;
+      n0 = tile / tpd;
+      nd = 1;
+      j0 = (tile % tpd) * A2_QT;
+      nq = (n0 < N) ? min(A2_QT, D1 - j0) : 0;
+    }
+    if (nd <= 0 || nq <= 0) return;
+    const int b = a.act_idx[slot];
+    const size_t qrow0 = ((size_t)slot * N + n0) * D1 + j0;   // first query row of this tile
+    const size_t drow0 = ((size_t)slot * N + n0) * D1;        // first row of the tile's first draft
+    if constexpr (MODE == ATT_STEP_SELF) {
+      const int f = a.front[b];
+      const int* tk = a.tok + (size_t)b * a.gen_ld;
+      const int pad = a.pad;
+      const float* kc = a.kcache + (size_t)b * a.cache_seq_stride + hd;
+      const float* vc = a.vcache + (size_t)b * a.cache_seq_stride + hd;
+      const float* kb = a.k + drow0 * a.ldkv + hd;
+      const float* vb = a.v + drow0 * a.ldkv + hd;
+      const int ld = a.ldkv, dd = a.d;
+      const int nB = (D1 <= A2_QT) ? nd * D1 : min(D1, j0 + nq);
+      attn2_core(a.q + qrow0 * a.ldq + hd, a.ldq, nq, f + nB,
+                 [=](int key, const float*& kp, const float*& vp) {
+                   const bool cached = key < f;
+                   const size_t off = cached ? (size_t)key * dd : (size_t)(key - f) * ld;
+                   kp = (cached ? kc : kb) + off;
+                   vp = (cached ? vc : vb) + off;
+                 },
+                 [=](int key) {
+                   if (key < f) return tk[key] != pad ? A2_ALL : -1;
+                   const int kj = key - f;                     // row inside the tile's drafts
+                   const int kd = kj / D1, kp = kj - kd * D1;
+                   if (kp == 0 && tk[f] == pad) return -1;     // the front token itself is a PAD key
+                   return (kd << 16) | kp;
+                 },
+                 [=](int qi) { const int qd = qi / D1; return (qd << 16) | (j0 + qi - qd * D1); },
+                 a.out + qrow0 * a.d + hd, a.d, a.scale, lds);
+    } else {
+      const size_t mrow0 = (size_t)b * a.Lk;
+      const uint8_t* kv = a.key_pad + mrow0;
+      const float* kb = a.k + mrow0 * a.ldkv + hd;
+      const float* vb = a.v + mrow0 * a.ldkv + hd;
+      const int ld = a.ldkv;
+      attn2_core(a.q + qrow0 * a.ldq + hd, a.ldq, nq, a.Lk,
+                 [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
+                 [=](int key) { return kv[key] != 0 ? A2_ALL : -1; }, q_any,
+                 a.out + qrow0 * a.d + hd, a.d, a.scale, lds);
+    }
   }
 }
 
