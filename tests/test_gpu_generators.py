@@ -1,0 +1,168 @@
+"""Every generator of the HIP path against the reference's golden token outputs (tiny model) and against the
+oracle at full model size (d=256, 8 heads, FFN 2048, 4+4) on weights trained here on the fixture reactions."""
+import numpy as np
+import pytest
+import torch
+
+from util_models import load_npz, tiny_state, fixture_tokens, upto_eos, PAD, BOS, EOS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tta():
+    import translation_transformer_amd as t
+    assert t.lib().ttx_device_count() >= 1
+    return t
+
+
+@pytest.fixture(scope="module")
+def tiny(tta):
+    st, cfg = tiny_state()
+    return tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+
+
+@pytest.fixture(scope="module")
+def full_state_trained():
+    """Full-size weights overfit on the 10 fixture pairs (stock torch training on the GPU: set-up only)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from tools.train_synth import TrainModel
+    src, tgt, _, V = fixture_tokens()
+    torch.manual_seed(1234)
+    model = TrainModel(vocab=V).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+    crit = torch.nn.CrossEntropyLoss()
+    s, t = src.cuda(), tgt.cuda()
+    model.train()
+    for step in range(600):
+        loss = crit(model(s, t[:, :-1]).reshape(-1, V), t[:, 1:].reshape(-1))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if loss.item() < 5e-3:
+            break
+    print("full-size fixture model: steps", step, "loss", loss.item())
+    assert loss.item() < 0.05
+    return {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+
+
+@pytest.fixture(scope="module")
+def full_pair(tta, full_state_trained):
+    from oracle.model import OracleTransformer, config_from_state
+    native = tta.NativeTransformer(full_state_trained, 8, 0, device=0)
+    oracle = OracleTransformer(config_from_state(full_state_trained, 8), full_state_trained)
+    return native, oracle
+
+
+def test_greedy_matches_reference(tta, tiny):
+    gold = load_npz("gen_greedy.npz")
+    src, _, _, _ = fixture_tokens()
+    for bsz in (1, 4, 10):
+        for max_len in (150, 40):
+            g = tta.TranslationInferenceGreedy(tiny, max_len, PAD, BOS, EOS)
+            for i in range(0, 10, bsz):
+                out = g.generate(src[i:i + bsz].cuda()).cpu().numpy()
+                ref = gold[f"b{bsz}_m{max_len}_tokens"][i:i + bsz]
+                assert out.shape == (min(bsz, 10 - i), 1, max_len)
+                for a, b in zip(out[:, 0], ref[:, 0]):
+                    assert upto_eos(a) == upto_eos(b)
+            assert g.model_calls_num == int(gold[f"b{bsz}_m{max_len}_calls"])
+
+
+def test_beam_matches_reference(tta, tiny):
+    gold = load_npz("gen_beam.npz")
+    src, _, _, _ = fixture_tokens()
+    for bsz, beam in ((1, 5), (4, 5), (10, 3), (5, 10)):
+        g = tta.TranslationInferenceBeamSearch(tiny, beam, 150, PAD, BOS, EOS)
+        for bi, i in enumerate(range(0, 10, bsz)):
+            out = g.generate(src[i:i + bsz].cuda()).cpu().numpy()
+            np.testing.assert_array_equal(out, gold[f"b{bsz}_k{beam}_batch{bi}"])
+        assert g.model_calls_num == int(gold[f"b{bsz}_k{beam}_calls"])
+
+
+@pytest.mark.parametrize("smart", [False, True])
+def test_beam_speculative_matches_reference(tta, tiny, smart):
+    """Top-1 hypothesis of every source must be token-identical to the reference.  Lower-ranked hypotheses are
+    ranked by fp32 sums of log-probabilities whose gaps on this overfit tiny model go down to 1.3e-4 (measured with
+    the oracle), i.e. the size of the accumulated fp32 difference between the HIP and the CPU forward (logits agree
+    to ~1.5e-5 per position), so a near-tie may swap: they must still agree for >= 90 % of the hypotheses."""
+    gold = load_npz("gen_spec_beam.npz")
+    src, _, c, V = fixture_tokens()
+    ci, same, total = 0, 0, 0
+    while f"smart{int(smart)}_case{ci}_rows" in gold:
+        key = f"smart{int(smart)}_case{ci}"
+        rows = gold[key + "_rows"].tolist()
+        bsz, nbest, N, D = gold[key + "_params"].tolist()
+        g = tta.TranslationInferenceBeamSearchSpeculative(tiny, 150, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=400)
+        exact = True
+        for bi, i in enumerate(range(0, len(rows), bsz)):
+            sel = src[rows[i:i + bsz]]
+            width = int((sel != PAD).sum(1).max())
+            out = g.generate(sel[:, :width].cuda()).cpu().numpy()
+            ref = gold[f"{key}_batch{bi}"]
+            assert out.shape[:2] == ref.shape[:2]
+            for b in range(out.shape[0]):
+                assert upto_eos(out[b, 0]) == upto_eos(ref[b, 0]), (key, bi, b)
+                for k in range(out.shape[1]):
+                    eq = upto_eos(out[b, k]) == upto_eos(ref[b, k])
+                    same += int(eq)
+                    total += 1
+                    exact &= eq
+        if exact:
+            assert g.model_calls_num == int(gold[key + "_calls"])
+            assert g.accepted_tokens_num == int(gold[key + "_accepted"])
+            assert g.produced_non_pad_tokens == int(gold[key + "_produced"])
+        ci += 1
+    print(f"beam-speculative smart={smart}: {same}/{total} hypotheses token-identical to the reference")
+    assert same >= 0.9 * total
+
+
+def test_full_size_greedy_speculative_matches_oracle(tta, full_pair):
+    from oracle.decoding import GreedySpeculativeOracle, GreedyOracle
+    native, oracle = full_pair
+    src, tgt, c, _ = fixture_tokens()
+    ref_greedy = GreedyOracle(oracle, 200, PAD, BOS, EOS).generate(src).numpy()[:, 0]
+    for N, D in ((3, 10), (1, 10), (7, 5), (23, 17)):
+        ref = GreedySpeculativeOracle(oracle, 200, D, N, PAD, BOS, EOS, c)
+        exp = ref.generate(src)
+        g = tta.TranslationInferenceGreedySpeculative(native, 200, D, N, PAD, BOS, EOS, c)
+        out = g.generate(src.cuda()).cpu()
+        assert torch.equal(out, exp), (N, D)
+        assert g.model_calls_num == ref.model_calls_num
+        for a, b in zip(out[:, 0].numpy(), ref_greedy):      # speculative == plain greedy, token for token
+            assert upto_eos(a) == upto_eos(b)
+    # and the fixture targets themselves (the model is overfit on them)
+    hit = sum(upto_eos(o) == upto_eos(t) for o, t in zip(out[:, 0].numpy(), tgt.numpy()))
+    assert hit >= 9
+
+
+def test_full_size_greedy_and_beam_match_oracle(tta, full_pair):
+    from oracle.decoding import GreedyOracle, BeamSearchOracle
+    native, oracle = full_pair
+    src, _, _, _ = fixture_tokens()
+    exp = GreedyOracle(oracle, 200, PAD, BOS, EOS).generate(src[:5]).numpy()
+    out = tta.TranslationInferenceGreedy(native, 200, PAD, BOS, EOS).generate(src[:5].cuda()).cpu().numpy()
+    for a, b in zip(out[:, 0], exp[:, 0]):
+        assert upto_eos(a) == upto_eos(b)
+    expb = BeamSearchOracle(oracle, 5, 200, PAD, BOS, EOS).generate(src[:4]).numpy()
+    outb = tta.TranslationInferenceBeamSearch(native, 5, 200, PAD, BOS, EOS).generate(src[:4].cuda()).cpu().numpy()
+    for b in range(4):
+        assert upto_eos(outb[b, 0]) == upto_eos(expb[b, 0])     # top-1 hypothesis identical
+
+
+def test_full_size_beam_speculative_matches_oracle(tta, full_pair):
+    from oracle.spec_beam import BeamSearchSpeculativeOracle
+    native, oracle = full_pair
+    src, _, c, V = fixture_tokens()
+    rows = [0, 2, 4, 6]
+    sel = src[rows]
+    sel = sel[:, :int((sel != PAD).sum(1).max())]
+    for smart in (False, True):
+        ref = BeamSearchSpeculativeOracle(oracle, 200, 5, 10, 7, V, smart, PAD, BOS, EOS, c, max_steps=300)
+        exp = ref.generate(sel).numpy()
+        g = tta.TranslationInferenceBeamSearchSpeculative(native, 200, 5, 10, 7, V, smart, PAD, BOS, EOS, c, max_steps=300)
+        out = g.generate(sel.cuda()).cpu().numpy()
+        for b in range(len(rows)):
+            assert upto_eos(out[b, 0]) == upto_eos(exp[b, 0]), (smart, b)

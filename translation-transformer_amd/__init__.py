@@ -3,4 +3,5 @@ Academich/translation-transformer.  Import as ``translation_tran
 shim at the repository root (the directory name carries a hyphen)."""
 from ._native import build, lib, TtxError, ReferenceError_  # noqa: F401
 from .model import NativeTransformer, reference_pe_table  # noqa: F401
-from .decoding import TranslationInferenceGreedySpeculative  # noqa: F401
+from .decoding import (TranslationInferenceGreedySpeculative, TranslationInferenceGreedy,  # noqa: F401
+                       TranslationInferenceBeamSearch, TranslationInferenceBeamSearchSpeculative)

@@ -709,31 +709,35 @@ struct GenCtx {
   KvCopyArgs kc;
 };
 
-static int launch_accept_and_commit(ttx_session* s, hipStream_t st, const GenCtx& g) {
-  hipLaunchKernelGGL(k_accept, dim3(1), dim3(256), 0, st, g.la);
+static int launch_accept_and_commit(ttx_session* s, hipStream_t st, const GenCtx& g, bool greedy) {
+  if (greedy) hipLaunchKernelGGL(k_greedy_accept, dim3(1), dim3(256), 0, st, g.la);
+  else hipLaunchKernelGGL(k_accept, dim3(1), dim3(256), 0, st, g.la);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_kvcopy, dim3(g.k.B, s->m->cfg.num_decoder_layers), dim3(256), 0, st, g.kc);
   HIP_TRY(hipGetLastError());
   return TTX_OK;
 }
 
-extern "C" int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_src, int B, int Ls,
-                                               const ttx_gen_params* p, int64_t* d_out, ttx_gen_stats* stats,
-                                               void* stream) {
-  if (!s || !d_src || !p || !d_out || B <= 0 || Ls <= 1) return fail(TTX_ERR_INVALID, "bad argument to ttx_greedy_speculative_generate");
+static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p, int64_t* d_out,
+                           ttx_gen_stats* stats, void* stream, bool greedy) {
+  if (!s || !d_src || !p || !d_out || B <= 0 || Ls <= 1) return fail(TTX_ERR_INVALID, "bad argument to a generate call");
   const ttx_model* m = s->m;
   const ttx_config& c = m->cfg;
-  if (p->n_drafts <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
-  if (p->max_len < 1) return fail(TTX_ERR_REFERENCE, "The minimum draft length must not be greater than the maximum draft length");
-  if (p->pad_token == p->replace_token || p->eos_token == p->replace_token || p->eos_token == p->pad_token)
-    return fail(TTX_ERR_REFERENCE, "pad, eos and replace tokens must be pairwise different");
-  if (p->draft_len <= 0) return fail(TTX_ERR_REFERENCE, "Number of speculative tokens must be a positive integer.");
-  if (p->draft_len > p->max_len) return fail(TTX_ERR_REFERENCE, "draft_len beyond max_len: the reference's scatter shapes disagree");
+  if (!greedy) {
+    if (p->n_drafts <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
+    if (p->max_len < 1) return fail(TTX_ERR_REFERENCE, "The minimum draft length must not be greater than the maximum draft length");
+    if (p->pad_token == p->replace_token || p->eos_token == p->replace_token || p->eos_token == p->pad_token)
+      return fail(TTX_ERR_REFERENCE, "pad, eos and replace tokens must be pairwise different");
+    if (p->draft_len <= 0) return fail(TTX_ERR_REFERENCE, "Number of speculative tokens must be a positive integer.");
+    if (p->draft_len > p->max_len) return fail(TTX_ERR_REFERENCE, "draft_len beyond max_len: the reference's scatter shapes disagree");
+  } else if (p->max_len < 1) {
+    return fail(TTX_ERR_INVALID, "max_len must be positive");
+  }
   if (p->pad_token != c.pad_token) return fail(TTX_ERR_INVALID, "generator pad token differs from the model's");
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(m->device));
   const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
-  const int N = p->n_drafts, D = p->draft_len, D1 = D + 1;
+  const int N = greedy ? 1 : p->n_drafts, D = greedy ? 0 : p->draft_len, D1 = D + 1;
   const int max_len = p->max_len;
   if (max_len + D + 2 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len + draft_len exceeds the positional table");
 
@@ -747,7 +751,7 @@ extern "C" int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_
   TTX_TRY(ensure(s->src_valid, (size_t)B * Ls, st));
   TTX_TRY(ensure(s->memory, (size_t)B * Ls * d * 4, st));
   TTX_TRY(ensure(s->memkv, (size_t)B * Ls * Ld * 2 * d * 4, st));
-  TTX_TRY(ensure(s->drafts, (size_t)B * N * D * 4, st));
+  TTX_TRY(ensure(s->drafts, (size_t)B * N * std::max(D, 1) * 4, st));
   TTX_TRY(ensure(s->gen, (size_t)B * g.k.gen_ld * 4, st));
   TTX_TRY(ensure(s->front, (size_t)B * 4, st));
   TTX_TRY(ensure(s->act_idx, (size_t)B * 4, st));
@@ -769,8 +773,9 @@ extern "C" int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_
   TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv.as<float>(),
                       Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0));
   // drafts from src[:, 1:] (:64-73): min_draft_len 1, max_draft_len max_len
-  TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls, 1, B, Ls - 1, N, D, p->eos_token, p->pad_token,
-                                  p->replace_token, s->drafts.as<int>()));
+  if (!greedy)
+    TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls, 1, B, Ls - 1, N, D, p->eos_token, p->pad_token,
+                                    p->replace_token, s->drafts.as<int>()));
 
   g.la.st = s->state.as<DecState>(); g.la.act_idx = s->act_idx.as<int>(); g.la.front = s->front.as<int>();
   g.la.gen = s->gen.as<int>(); g.la.gen_ld = g.k.gen_ld; g.la.drafts = s->drafts.as<int>(); g.la.pred = s->pred.as<int>();
@@ -798,8 +803,12 @@ extern "C" int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_
     if (*s->host_flag) break;
     if (launched > max_len + 2) return fail(TTX_ERR_HIP, "greedy-speculative loop failed to terminate");
     TTX_TRY(run_step(s, st, g.k));
-    TTX_TRY(launch_accept_and_commit(s, st, g));
+    TTX_TRY(launch_accept_and_commit(s, st, g, greedy));
     ++launched;
+  }
+  if (greedy) {
+    hipLaunchKernelGGL(k_gen_to_out, dim3(cdiv(B * max_len, 256)), dim3(256), 0, st, s->gen.as<int>(), g.k.gen_ld, d_out, B, max_len);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(s->ev_c, st));
   HIP_TRY(hipMemcpyAsync(s->host_state, s->state.as<DecState>(), sizeof(DecState), hipMemcpyDeviceToHost, st));
@@ -830,10 +839,15 @@ extern "C" int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_
   return TTX_OK;
 }
 
+extern "C" int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_src, int B, int Ls,
+                                               const ttx_gen_params* p, int64_t* d_out, ttx_gen_stats* stats,
+                                               void* stream) {
+  return generate_common(s, d_src, B, Ls, p, d_out, stats, stream, false);
+}
+
 extern "C" int ttx_greedy_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p,
                                    int64_t* d_out, ttx_gen_stats* stats, void* stream) {
-  (void)s; (void)d_src; (void)B; (void)Ls; (void)p; (void)d_out; (void)stats; (void)stream;
-  return fail(TTX_ERR_INVALID, "ttx_greedy_generate: not built yet in this revision");
+  return generate_common(s, d_src, B, Ls, p, d_out, stats, stream, true);
 }
 
 extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches) {

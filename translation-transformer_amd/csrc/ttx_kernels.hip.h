@@ -1042,6 +1042,46 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
   }
 }
 
+// Plain greedy decoding (standard_decoding.py:45-53) on the same step machinery with N = 1, D = 0: every row
+// appends its argmax token each step; nothing retires; the loop ends when every row emitted EOS or PAD at
+// the same step, or after max_len - 1 steps.
+__global__ __launch_bounds__(256) void k_greedy_accept(LoopArgs a) {
+  __shared__ int s_running;
+  DecState* st = a.st;
+  const int Bc = st->n_active;
+  if (Bc == 0) return;
+  if (threadIdx.x == 0) s_running = 0;
+  __syncthreads();
+  const int f = a.front[0];                        // all rows share the same front in greedy decoding
+  for (int b = threadIdx.x; b < Bc; b += blockDim.x) {
+    const int t = a.pred[b];
+    a.gen[(size_t)b * a.gen_ld + f + 1] = t;
+    a.front[b] = f + 1;
+    a.rec[b] = CopyRec{b, 0, 0, f};
+    if (t != a.eos && t != a.pad) s_running = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->n_copy = Bc;
+    st->steps += 1;
+    st->produced += Bc;
+    st->verified_positions += Bc;
+    st->kv_prefix_positions += (long long)Bc * f;
+    st->src_positions += (long long)Bc * a.Ls;
+    st->width = f + 2;
+    const int stop = (!s_running || f + 1 >= a.max_len - 1) ? 1 : 0;
+    st->stop = stop;
+    if (stop) { st->n_active = 0; st->r_rows = 0; st->m_rows = 0; }
+    *a.host_flag = stop;
+    __threadfence_system();
+  }
+}
+
+__global__ void k_gen_to_out(const int* gen, int gen_ld, int64_t* out, int B, int max_len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * max_len) out[i] = gen[(size_t)(i / max_len) * gen_ld + (i % max_len)];
+}
+
 // Copy the K/V rows of the accepted positions (chosen draft, j = 0..nacc) from the step's packed
 // QKV buffer of every decoder layer into the KV cache at positions front_old + j.
 struct KvCopyArgs {
