@@ -125,26 +125,7 @@ def main():
     from tools.synth import SynthReactions, batches, PAD, BOS, EOS, C_TOK, V
 
     # ---- weights: rank 0 trains/loads, one RCCL broadcast of the packed fp32 blob
-    names = shapes = None
-    if rank == 0:
-        sd = get_weights(a.train_steps, dev)
-        names = list(sd.keys())
-        shapes = [tuple(sd[k].shape) for k in names]
-        flat = torch.cat([sd[k].reshape(-1).float() for k in names]).to(dev)
-    if world > 1:
-        meta = [names, shapes]
-        dist.broadcast_object_list(meta, src=0)
-        names, shapes = meta
-        n = sum(int(np.prod(s)) for s in shapes)
-        if rank != 0:
-            flat = torch.empty(n, dtype=torch.float32, device=dev)
-        dist.broadcast(flat, src=0)
-    host = flat.cpu()
-    sd, off = {}, 0
-    for k, s in zip(names, shapes):
-        n = int(np.prod(s))
-        sd[k] = host[off:off + n].reshape(s)
-        off += n
+    sd = tta.dist.broadcast_state_dict(get_weights(a.train_steps, dev) if rank == 0 else None, dev, dist)
     model = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=PAD, device=local_rank)
     cfg = {"d": model.emb_dim, "F": model.ff_dim, "V": model.tgt_vocab_size, "Le": model.num_enc_layers,
            "Ld": model.num_dec_layers}
@@ -182,11 +163,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- prediction gather: one collective at the end, int16 tokens
-    preds = torch.cat([o[:, 0, :] for o in outs]).to(torch.int16)
-    if dist:
-        gathered = [torch.empty_like(preds) for _ in range(world)] if rank == 0 else None
-        dist.gather(preds, gathered, dst=0)
+    # ---- prediction gather: one collective at the end
+    preds = torch.cat([o[:, 0, :] for o in outs])
+    gathered = tta.dist.gather_predictions(preds.unsqueeze(1), world * preds.shape[0], dist)
+    if rank == 0:
+        assert gathered.shape[0] == world * preds.shape[0]
     n_reactions = world * len(timed) * a.batch_size
     stats = dict(gen.stats_total)
     stats["model_calls"] = gen.model_calls_num

@@ -5,3 +5,5 @@ from ._native import build, lib, TtxError, ReferenceError_  # noqa: F401
 from .model import NativeTransformer, reference_pe_table  # noqa: F401
 from .decoding import (TranslationInferenceGreedySpeculative, TranslationInferenceGreedy,  # noqa: F401
                        TranslationInferenceBeamSearch, TranslationInferenceBeamSearchSpeculative)
+from .lightning_model import VanillaEncoderDecoderTransformerLightning, run_predict  # noqa: F401,E402
+from . import dist  # noqa: F401,E402

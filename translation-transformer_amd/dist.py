@@ -1,0 +1,77 @@
+"""Multi-GPU layer: the test set shards embarrassingly over ranks, one process per GPU.
+Two collectives per run and none per step:  C1 one broadcast of the packed fp32 weights from rank 0,
+C2 one gather of the predictions to rank 0.  Backend "nccl" is RCCL over xGMI on ROCm; the same code runs
+on "gloo" for the CPU tests (tests/test_dist_sharding.py)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous slice [lo, hi) of an unshuffled test set for `rank` (no duplication, unlike Lightning's
+    DistributedSampler which pads shards to equal length)."""
+    per = math.ceil(n_items / world) if world > 0 else n_items
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+def broadcast_state_dict(state: dict | None, device: torch.device | str, dist=None, src: int = 0) -> dict:
+    """C1.  Rank `src` passes its state dict (name -> tensor); every rank returns the same dict (CPU fp32).
+    One broadcast of names/shapes (tiny, object) + ONE broadcast of the flat fp32 blob (46 MB for the MIT model)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return {k: torch.as_tensor(v).float().cpu() for k, v in state.items()}
+    rank = dist.get_rank()
+    meta = [None]
+    if rank == src:
+        names = list(state.keys())
+        meta = [[(k, tuple(state[k].shape)) for k in names]]
+        flat = torch.cat([torch.as_tensor(state[k]).reshape(-1).float() for k in names]).to(device)
+    dist.broadcast_object_list(meta, src=src)
+    total = sum(int(np.prod(s)) for _, s in meta[0])
+    if rank != src:
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+    dist.broadcast(flat, src=src)
+    host = flat.cpu()
+    out, off = {}, 0
+    for k, s in meta[0]:
+        n = int(np.prod(s))
+        out[k] = host[off:off + n].reshape(s)
+        off += n
+    return out
+
+
+def gather_predictions(local: torch.Tensor, n_items: int, dist=None, dst: int = 0, pad_value: int = 0):
+    """C2.  `local` is this rank's [n_local, N, L] integer predictions for its shard_bounds slice; returns the
+    [n_items, N, Lmax] tensor in original order on rank `dst` (None elsewhere).  Token ids travel as int32."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = math.ceil(n_items / world)
+    dt = torch.int32            # token ids; every rank must agree on the wire type
+    width = torch.tensor([local.shape[2] if local.numel() else 0], dtype=torch.int64, device=local.device)
+    dist.all_reduce(width, op=dist.ReduceOp.MAX)
+    W = int(width.item())
+    buf = torch.full((per, local.shape[1], W), pad_value, dtype=dt, device=local.device)
+    buf[:local.shape[0], :, :local.shape[2]] = local.to(dt)
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, parts, dst=dst)
+    if rank != dst:
+        return None
+    out = []
+    for r, p in enumerate(parts):
+        lo, hi = shard_bounds(n_items, r, world)
+        out.append(p[:hi - lo])
+    return torch.cat(out).to(torch.int64)
+
+
+def sum_counters(values: dict, device, dist=None) -> dict:
+    """Additive per-rank counters (model calls, accepted tokens, ...) summed over ranks."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(values)
+    keys = sorted(values)
+    t = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return {k: t[i].item() for i, k in enumerate(keys)}

@@ -1,0 +1,196 @@
+"""Lightning surface of the reference kept for the inference path:
+
+    VanillaEncoderDecoderTransformerLightning   <- src/model/lightning_model.py:22-243
+
+Same ``init_args`` (lightning_model.py:24-51), same ``predict_step`` / ``on_predict_start`` /
+``on_predict_end`` hooks and JSON report keys, same attributes the PredictionWriter callback reads
+(``tgt_tokenizer``; src/callbacks.py:49-64), same checkpoint key layout (``model.`` + the names of
+SURVEY §8(b) B6) — so ``main.py predict -c cfg.yaml --ckpt_path ...`` runs unchanged once the YAML's
+``model.class_path`` points here.  Training hooks are out of scope and raise.
+
+``self.model`` is a parameter container with the reference's module names (so Lightning's checkpoint loading
+fills it); its torch ``forward`` is never called — all arithmetic runs in libttx_hip.so through the
+NativeTransformer built from those parameters when prediction starts.  The module imports without
+pytorch_lightning (absent in the build container); then a minimal stand-in base class is used and
+``run_predict`` below drives the hooks.
+"""
+from __future__ import annotations
+
+import datetime
+import json
+from pathlib import Path
+from timeit import default_timer as timer
+from types import SimpleNamespace
+from typing import Any
+
+import torch
+from torch import nn
+
+try:  # pragma: no cover - depends on the environment
+    from pytorch_lightning import LightningModule
+    HAVE_LIGHTNING = True
+except Exception:  # pragma: no cover
+    HAVE_LIGHTNING = False
+
+    class LightningModule(nn.Module):  # minimal stand-in: hparams + the hooks this file uses
+        def __init__(self):
+            super().__init__()
+            self.hparams = SimpleNamespace()
+            self.trainer = None
+
+        def save_hyperparameters(self, ignore=()):
+            import inspect
+            frame = inspect.currentframe().f_back
+            args = {k: v for k, v in frame.f_locals.items() if k not in ("self", "__class__") and k not in ignore}
+            self.hparams = SimpleNamespace(**args)
+
+from .model import NativeTransformer
+from . import decoding as D
+
+
+class _Emb(nn.Module):
+    def __init__(self, vocab, d, pad):
+        super().__init__()
+        self.embedding = nn.Embedding(vocab, d, padding_idx=pad)
+
+
+class WeightContainer(nn.Module):
+    """Parameters only, named exactly like the reference's VanillaTransformer (src/model/modules.py:40-84)."""
+
+    def __init__(self, src_vocab, tgt_vocab, n_enc, n_dec, d, heads, ff, share, src_pad, tgt_pad):
+        super().__init__()
+        self.src_pad_token_i, self.tgt_pad_token_i = src_pad, tgt_pad
+        self.emb_dim, self.num_heads = d, heads
+        self.src_token_featurizer = _Emb(src_vocab, d, src_pad)
+        self.tgt_token_featurizer = self.src_token_featurizer if share else _Emb(tgt_vocab, d, tgt_pad)
+        enc = nn.TransformerEncoder(nn.TransformerEncoderLayer(d, heads, ff, 0.0, "relu", 1e-5, True, False), n_enc,
+                                    nn.LayerNorm(d, eps=1e-5), enable_nested_tensor=False)
+        dec = nn.TransformerDecoder(nn.TransformerDecoderLayer(d, heads, ff, 0.0, "relu", 1e-5, True, False), n_dec,
+                                    nn.LayerNorm(d, eps=1e-5))
+        self.transformer = nn.Transformer(d_model=d, nhead=heads, batch_first=True, custom_encoder=enc, custom_decoder=dec)
+        self.next_token_classifier = nn.Linear(d, tgt_vocab)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("the torch modules here only hold parameters; the forward pass runs in libttx_hip.so")
+
+
+class VanillaEncoderDecoderTransformerLightning(LightningModule):
+    def __init__(self,
+                 src_tokenizer=None, tgt_tokenizer=None,
+                 embedding_dim: int = 128, feedforward_dim: int = 256, num_encoder_layers: int = 3,
+                 num_decoder_layers: int = 3, num_heads: int = 4, dropout_rate: float = 0.0, activation: str = "relu",
+                 share_embeddings: bool = False,
+                 learning_rate: float = 3e-4, weight_decay: float = 0., scheduler: str = "const", warmup_steps: int = 0,
+                 generation: str = "beam_search", beam_size: int = 0, max_len: int = 0, n_drafts: int = 0,
+                 draft_len: int = 0, smart_drafts_mode: bool = True,
+                 report_prediction_time: bool = True, report_prediction_file: str | None = None):
+        super().__init__()
+        self.save_hyperparameters(ignore=["src_tokenizer", "tgt_tokenizer"])
+        assert src_tokenizer is not None, "source tokenizer not provided"
+        assert tgt_tokenizer is not None, "target tokenizer not provided"
+        assert activation == "relu", "the HIP path implements the reference configs' ReLU feed-forward"
+        self.src_tokenizer, self.tgt_tokenizer = src_tokenizer, tgt_tokenizer
+        self.src_vocab_size, self.tgt_vocab_size = src_tokenizer.n_tokens, tgt_tokenizer.n_tokens
+        self.src_pad_token_i, self.src_bos_token_i, self.src_eos_token_i = (
+            src_tokenizer.pad_token_idx, src_tokenizer.bos_token_idx, src_tokenizer.eos_token_idx)
+        self.tgt_pad_token_i, self.tgt_bos_token_i, self.tgt_eos_token_i = (
+            tgt_tokenizer.pad_token_idx, tgt_tokenizer.bos_token_idx, tgt_tokenizer.eos_token_idx)
+        self.model = WeightContainer(self.src_vocab_size, self.tgt_vocab_size, num_encoder_layers, num_decoder_layers,
+                                     embedding_dim, num_heads, feedforward_dim, share_embeddings,
+                                     self.src_pad_token_i, self.tgt_pad_token_i)
+        if generation not in ("greedy", "beam_search", "greedy_speculative", "beam_search_speculative"):
+            options = ", ".join(["beam_search", "greedy", "greedy_speculative", "beam_search_speculative"])
+            raise ValueError(f'Unknown generation option {generation}. Options are {options}.')
+        if generation == "greedy_speculative":
+            assert draft_len > 0, "Number of speculative tokens must be a positive integer."
+        self.native: NativeTransformer | None = None
+        self.generator = None
+        self.report_prediction_time = report_prediction_time
+        self.prediction_start_time = None
+
+    # -- native path ------------------------------------------------------------------------------
+    def build_native(self, device: int | str | torch.device | None = None) -> None:
+        """(Re)build the HIP model + generator from the current parameters (call after loading a checkpoint)."""
+        if device is None:
+            p = next(self.model.parameters())
+            device = p.device if p.is_cuda else torch.device("cuda:0")
+        self.native = NativeTransformer(self.model.state_dict(), self.hparams.num_heads, self.tgt_pad_token_i, device=device)
+        self.generator = self._create_generator()
+        print(self.generator)
+
+    def _create_generator(self):
+        h, m = self.hparams, self.native
+        common = dict(pad_token=self.tgt_pad_token_i, bos_token=self.tgt_bos_token_i, eos_token=self.tgt_eos_token_i)
+        if h.generation == "greedy":
+            return D.TranslationInferenceGreedy(m, max_len=h.max_len, **common)
+        if h.generation == "beam_search":
+            return D.TranslationInferenceBeamSearch(m, beam_size=h.beam_size, max_len=h.max_len, **common)
+        if h.generation == "greedy_speculative":
+            return D.TranslationInferenceGreedySpeculative(m, max_len=h.max_len, draft_len=h.draft_len, n_drafts=h.n_drafts,
+                                                           replace_token=self.tgt_tokenizer.encoder_dict["c"], **common)
+        return D.TranslationInferenceBeamSearchSpeculative(
+            m, vocab_size=self.tgt_vocab_size, max_len=h.max_len, n_best=h.beam_size, draft_len=h.draft_len,
+            n_drafts=h.n_drafts, C_token=self.tgt_tokenizer.encoder_dict["c"], smart_drafts_mode=h.smart_drafts_mode, **common)
+
+    # -- hooks kept from the reference ---------------------------------------------------------------
+    def predict_step(self, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> Any:
+        if self.generator is None:
+            self.build_native()
+        return self.generator.generate(batch["src_tokens"])
+
+    def on_predict_start(self) -> None:
+        self.build_native()                      # weights are final here (Trainer.predict has loaded --ckpt_path)
+        if self.report_prediction_time:
+            self.prediction_start_time = timer()
+
+    def on_predict_end(self) -> None:
+        if not self.report_prediction_time:
+            return
+        torch.cuda.synchronize()
+        elapsed = datetime.timedelta(seconds=timer() - self.prediction_start_time)
+        h = self.hparams
+        dm = getattr(self.trainer, "datamodule", None)
+        report = {
+            "algorithm": h.generation,
+            "batch_size": getattr(dm, "batch_size", None),
+            "tgt_test_path": str(getattr(dm, "tgt_test_path", None)),
+            "max_len": h.max_len,
+            "total_seconds": round(elapsed.total_seconds(), 4),
+            "model_calls": self.generator.model_calls_num,
+            "seconds_per_model_call": round(elapsed.total_seconds() / max(1, self.generator.model_calls_num), 4),
+        }
+        if h.generation in ("greedy_speculative", "beam_search_speculative"):
+            report["n_drafts"] = h.n_drafts
+            report["draft_len"] = h.draft_len
+            if h.generation == "beam_search_speculative":
+                report["accepted_tokens"] = self.generator.accepted_tokens_num
+                report["acceptance_rate"] = round(self.generator.accepted_tokens_num /
+                                                  max(1, self.generator.produced_non_pad_tokens), 4)
+        text = json.dumps(report)
+        print(text)
+        if h.report_prediction_file is not None:
+            Path(h.report_prediction_file).parent.mkdir(exist_ok=True)
+            with open(h.report_prediction_file, "a") as f:
+                print(text, file=f)
+
+    # -- out of scope ------------------------------------------------------------
+    def training_step(self, *a, **k):
+        raise NotImplementedError("training is outside the MI355X inference path; train with the reference")
+
+    validation_step = test_step = training_step
+
+
+def run_predict(module: VanillaEncoderDecoderTransformerLightning, batches, writer=None, datamodule=None) -> list:
+    """Stand-in for ``Trainer.predict`` when pytorch_lightning is absent: same hook order
+    (on_predict_start -> predict_step per batch -> writer.write_on_batch_end -> on_predict_end)."""
+    module.trainer = SimpleNamespace(datamodule=datamodule)
+    outs = []
+    with torch.inference_mode():
+        module.on_predict_start()
+        for i, batch in enumerate(batches):
+            pred = module.predict_step(batch, i)
+            if writer is not None:
+                writer.write_on_batch_end(module.trainer, module, pred, None, batch, i, 0)
+            outs.append(pred)
+        module.on_predict_end()
+    return outs
