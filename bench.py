@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--max-len", type=int, default=200)
     ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "2500")))
     ap.add_argument("--cpu-batches", type=int, default=1, help="batches of the workload timed on the host cores")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("TTX_INFLIGHT", "1")),
+                    help="batches decoded concurrently per GPU (1 = the reference's one-batch-at-a-time loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -144,6 +146,8 @@ def main():
     log("model ready; warmup")
     for b in warm:
         gen.generate(b)
+    if a.inflight > 1:     # warm every session of the pool (workspaces, graph capture)
+        gen.generate_many(warm * a.inflight, in_flight=a.inflight)
     log("warmup done", gen.model_calls_num, "calls")
     gen = make_gen(model)
     torch.cuda.synchronize()
@@ -151,7 +155,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = [gen.generate(b) for b in timed]
+    if a.inflight > 1:
+        outs = gen.generate_many(timed, in_flight=a.inflight)
+    else:
+        outs = [gen.generate(b) for b in timed]
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -181,7 +188,8 @@ def main():
         "config": {"workload": f"USPTO-MIT-shaped synthetic SMILES, greedy speculative draft_len={a.draft_len} "
                                f"n_drafts={a.n_drafts} bs={a.batch_size} max_len={a.max_len}, d=256 8h FFN2048 4+4 fp32, "
                                f"weights trained {a.train_steps} steps on the synthetic task",
-                   "reactions": n_reactions, "parallelism": f"test-set shards x{world}, no per-step collective"},
+                   "reactions": n_reactions, "parallelism": f"test-set shards x{world}, no per-step collective",
+                   "batches_in_flight_per_gpu": a.inflight},
         "model_calls": stats["model_calls"], "rows_finished_rank0": finished, "rows_rank0": int(preds.shape[0]),
         "accepted_per_step_per_row": stats["accepted_tokens"] / max(1, stats["produced_tokens"] - stats["accepted_tokens"]),
         "device_ms_encode_rank0": stats["encode_ms"], "device_ms_decode_rank0": stats["decode_ms"],

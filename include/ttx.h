@@ -138,6 +138,16 @@ int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_src, int B,
 int ttx_greedy_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p,
                         int64_t* d_out, ttx_gen_stats* stats, void* stream);
 
+/* Several batches in flight on one GPU (the scheduling SURVEY.md §8(f) #1 names; the reference's predict loop
+ * is strictly one batch at a time, src/model/lightning_model.py:209-212).  Batch i is decoded on
+ * sessions[i % n_sessions]; each session runs on its own internal stream that first waits for `stream`
+ * (the stream the inputs were produced on); the call returns when every output is complete.  Per-batch
+ * outputs and stats are identical to n_batches calls of ttx_greedy_speculative_generate. */
+int ttx_greedy_speculative_generate_many(ttx_session** sessions, int n_sessions, int n_batches,
+                                         const int64_t* const* d_src, const int* B, const int* Ls,
+                                         const ttx_gen_params* p, int64_t* const* d_out, ttx_gen_stats* stats,
+                                         void* stream);
+
 /* Timing of the dominant kernel for bench.py's roofline: summed HIP-event time (events recorded on the
  * launch stream around every k_gemm_tn launch) and launch count of the most recent generate call on this
  * session.  Only collected when the session was created with TTX_PROFILE_GEMM=1 in the environment. */

@@ -42,3 +42,20 @@ def test_unfinished_rows_stay_pad(tta, tiny):
         out = g.generate(src.cuda()).cpu().numpy()
         np.testing.assert_array_equal(out, gold[f"short_m{max_len}_tokens"])
         assert g.model_calls_num == int(gold[f"short_m{max_len}_calls"])
+
+
+def test_many_batches_in_flight_equal_one_at_a_time(tta, tiny):
+    src, _, c, _ = fixture_tokens()
+    g1 = tta.TranslationInferenceGreedySpeculative(tiny, 150, 10, 3, PAD, BOS, EOS, c)
+    batches = []
+    for lo, hi in ((0, 3), (3, 4), (4, 8), (8, 10), (0, 10), (5, 9)):
+        sel = src[lo:hi]
+        batches.append(sel[:, :int((sel != PAD).sum(1).max())].cuda())
+    ref = [g1.generate(b) for b in batches]
+    for in_flight in (1, 2, 4):
+        g2 = tta.TranslationInferenceGreedySpeculative(tiny, 150, 10, 3, PAD, BOS, EOS, c)
+        out = g2.generate_many(batches, in_flight=in_flight)
+        assert len(out) == len(ref)
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+        assert g2.model_calls_num == g1.model_calls_num

@@ -70,6 +70,9 @@ SYMBOLS = {
     "ttx_make_drafts": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
     "ttx_greedy_speculative_generate": (C.c_int, [_VP, _VP, _I, _I, C.POINTER(GenParams), _VP, C.POINTER(GenStats), _VP]),
     "ttx_greedy_generate": (C.c_int, [_VP, _VP, _I, _I, C.POINTER(GenParams), _VP, C.POINTER(GenStats), _VP]),
+    "ttx_greedy_speculative_generate_many": (C.c_int, [C.POINTER(_VP), _I, _I, C.POINTER(_VP), C.POINTER(C.c_int),
+                                                      C.POINTER(C.c_int), C.POINTER(GenParams), C.POINTER(_VP),
+                                                      C.POINTER(GenStats), _VP]),
     "ttx_last_kernel_profile": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -247,6 +249,13 @@ struct Buf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+struct GraphKey {
+  int B, Ls, N, D, max_len, greedy, kcap;
+  bool operator<(const GraphKey& o) const {
+    return std::tie(B, Ls, N, D, max_len, greedy, kcap) < std::tie(o.B, o.Ls, o.N, o.D, o.max_len, o.greedy, o.kcap);
+  }
+};
+
 struct ttx_session {
   ttx_model* m;
   std::vector<Buf*> all;
@@ -257,8 +266,15 @@ struct ttx_session {
   // full decoder
   Buf tok_tgt, mem_pad_tmp;
   // loop
-  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32;
-  int* host_flag = nullptr;        // pinned, written by k_accept
+  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf;
+  HostInfo* host_info = nullptr;   // pinned + device-mapped, written by the accept kernels
+  hipStream_t own_stream = nullptr; // used by the many-batches driver
+  uint64_t alloc_generation = 0;   // bumped whenever a workspace buffer moves (captured graphs hold raw pointers)
+  bool use_graphs = true;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  std::set<GraphKey> warmed;
+  hipEvent_t ev_done = nullptr;
+  void drop_graphs() { for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second); graphs.clear(); warmed.clear(); }
   DecState* host_state = nullptr;  // pinned copy target
   bool attn_attr_set = false;
   size_t attn_lds_limit = 0;
@@ -272,11 +288,14 @@ struct ttx_session {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
   ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
-                                 &kcache, &vcache, &src32}) all.push_back(b); }
+                                 &kcache, &vcache, &src32, &outbuf}) all.push_back(b); }
 };
+
+static thread_local uint64_t* g_alloc_gen = nullptr;   // alloc_generation of the session being sized
 
 static int ensure(Buf& b, size_t bytes, hipStream_t st) {
   if (bytes <= b.cap) return TTX_OK;
+  if (g_alloc_gen) ++*g_alloc_gen;
   if (b.p) {
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipDeviceSynchronize());
@@ -295,15 +314,17 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   HIP_TRY(hipSetDevice(m->device));
   ttx_session* s = new ttx_session();
   s->m = m;
-  if (hipHostMalloc((void**)&s->host_flag, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+  if (hipHostMalloc((void**)&s->host_info, sizeof(HostInfo), hipHostMallocMapped) != hipSuccess ||
       hipHostMalloc((void**)&s->host_state, sizeof(DecState), hipHostMallocDefault) != hipSuccess) {
     delete s;
     return fail(TTX_ERR_NOMEM, "hipHostMalloc failed");
   }
-  *s->host_flag = 0;
+  std::memset(s->host_info, 0, sizeof(HostInfo));
   HIP_TRY(hipEventCreate(&s->ev_a));
   HIP_TRY(hipEventCreate(&s->ev_b));
   HIP_TRY(hipEventCreate(&s->ev_c));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+  s->use_graphs = getenv("TTX_NO_GRAPH") == nullptr;
   const char* pf = getenv("TTX_PROFILE_GEMM");
   s->profile = pf && pf[0] == '1';
   s->gemm_v1 = getenv("TTX_GEMM_V1") != nullptr;
@@ -317,7 +338,10 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
   (void)hipDeviceSynchronize();
   for (Buf* b : s->all)
     if (b->p) (void)hipFree(b->p);
-  if (s->host_flag) (void)hipHostFree(s->host_flag);
+  if (s->host_info) (void)hipHostFree(s->host_info);
+  s->drop_graphs();
+  if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+  if (s->ev_done) (void)hipEventDestroy(s->ev_done);
   if (s->host_state) (void)hipHostFree(s->host_state);
   for (auto& e : s->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (s->ev_a) (void)hipEventDestroy(s->ev_a);
@@ -644,7 +668,7 @@ struct StepCtx {
   ttx_gen_params p;
 };
 
-static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k) {
+static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) {
   const ttx_model* m = s->m;
   const ttx_config& c = m->cfg;
   const int d = c.embedding_dim, F = c.feedforward_dim, H = c.num_heads, V = c.vocab_size, Ld = c.num_decoder_layers;
@@ -682,7 +706,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k) {
     a.tok = s->gen.as<int>(); a.pad = c.pad_token; a.st = dst; a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>();
     a.kcache = s->kcache.as<float>() + (size_t)l * cache_layer; a.vcache = s->vcache.as<float>() + (size_t)l * cache_layer;
     a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D1 = D1;
-    TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, k.B, H, k.N * D1, k.max_len, k.N, D1));
+    TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, k.B, H, k.N * D1, kcap, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
                     nullptr, x1, m_ptr, Mmax));
     TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, m_ptr, Mmax, d, d, false, 0, 0));
@@ -718,11 +742,23 @@ static int launch_accept_and_commit(ttx_session* s, hipStream_t st, const GenCtx
   return TTX_OK;
 }
 
-static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p, int64_t* d_out,
-                           ttx_gen_stats* stats, void* stream, bool greedy) {
+// One generate call in flight on one session: start (encoder, drafts, loop init) -> steps -> finish.
+struct GenJob {
+  ttx_session* s = nullptr;
+  hipStream_t st = nullptr;
+  GenCtx g{};
+  bool greedy = false;
+  int64_t* d_out = nullptr;
+  ttx_gen_stats* stats = nullptr;
+  int launched = 0;
+  int phase = 0;          // 0 idle, 1 running, 2 finishing
+  int batch = -1;
+};
+
+static int gen_validate(const ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p, const int64_t* d_out,
+                        bool greedy) {
   if (!s || !d_src || !p || !d_out || B <= 0 || Ls <= 1) return fail(TTX_ERR_INVALID, "bad argument to a generate call");
-  const ttx_model* m = s->m;
-  const ttx_config& c = m->cfg;
+  const ttx_config& c = s->m->cfg;
   if (!greedy) {
     if (p->n_drafts <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
     if (p->max_len < 1) return fail(TTX_ERR_REFERENCE, "The minimum draft length must not be greater than the maximum draft length");
@@ -734,19 +770,28 @@ static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, 
     return fail(TTX_ERR_INVALID, "max_len must be positive");
   }
   if (p->pad_token != c.pad_token) return fail(TTX_ERR_INVALID, "generator pad token differs from the model's");
-  hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipSetDevice(m->device));
+  const int D = greedy ? 0 : p->draft_len;
+  if (p->max_len + D + 2 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len + draft_len exceeds the positional table");
+  return TTX_OK;
+}
+
+static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p,
+                     int64_t* d_out, ttx_gen_stats* stats, bool greedy) {
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
   const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
   const int N = greedy ? 1 : p->n_drafts, D = greedy ? 0 : p->draft_len, D1 = D + 1;
   const int max_len = p->max_len;
-  if (max_len + D + 2 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len + draft_len exceeds the positional table");
-
-  GenCtx g{};
+  j.s = s; j.st = st; j.greedy = greedy; j.d_out = d_out; j.stats = stats; j.launched = 0;
+  GenCtx& g = j.g;
+  g = GenCtx{};
   g.k.B = B; g.k.Ls = Ls; g.k.N = N; g.k.D = D; g.k.max_len = max_len; g.k.p = *p;
   g.k.Lc = max_len + D1;           // cache positions per row (front + D < max_len + D)
   g.k.gen_ld = max_len + D + 2;
   const size_t Mmax = (size_t)B * N * D1;
 
+  const uint64_t gen_before = s->alloc_generation;
+  g_alloc_gen = &s->alloc_generation;
   TTX_TRY(ensure(s->tok_src, (size_t)B * Ls * 4, st));
   TTX_TRY(ensure(s->src_valid, (size_t)B * Ls, st));
   TTX_TRY(ensure(s->memory, (size_t)B * Ls * d * 4, st));
@@ -759,11 +804,16 @@ static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, 
   TTX_TRY(ensure(s->pred, Mmax * 4, st));
   TTX_TRY(ensure(s->state, sizeof(DecState), st));
   TTX_TRY(ensure(s->logits, Mmax * V * 4, st));
+  TTX_TRY(ensure(s->outbuf, (size_t)B * max_len * 8, st));
   TTX_TRY(ensure(s->kcache, (size_t)Ld * B * g.k.Lc * d * 4, st));
   TTX_TRY(ensure(s->vcache, (size_t)Ld * B * g.k.Lc * d * 4, st));
   // the encoder and the step share the activation buffers; size them for the larger of the two
-  TTX_TRY(ensure_acts(s, st, std::max(Mmax, (size_t)B * Ls), 1));
+  const size_t Macts = std::max(Mmax, (size_t)B * Ls);
+  TTX_TRY(ensure_acts(s, st, Macts, 1));
   TTX_TRY(ensure(s->qkv, std::max((size_t)Ld * Mmax, (size_t)B * Ls) * 3 * d * 4, st));
+  TTX_TRY(ensure(s->slab, sizeof(float) * 16 * Macts * d, st));   // no allocation may happen inside a graph capture
+  g_alloc_gen = nullptr;
+  if (s->alloc_generation != gen_before) s->drop_graphs();        // captured pointers are stale
 
   s->ev_used = 0;
   HIP_TRY(hipEventRecord(s->ev_a, st));
@@ -779,10 +829,10 @@ static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, 
 
   g.la.st = s->state.as<DecState>(); g.la.act_idx = s->act_idx.as<int>(); g.la.front = s->front.as<int>();
   g.la.gen = s->gen.as<int>(); g.la.gen_ld = g.k.gen_ld; g.la.drafts = s->drafts.as<int>(); g.la.pred = s->pred.as<int>();
-  g.la.rec = s->rec.as<CopyRec>(); g.la.out = d_out;
-  int* dev_flag = nullptr;
-  HIP_TRY(hipHostGetDevicePointer((void**)&dev_flag, s->host_flag, 0));
-  g.la.host_flag = dev_flag;
+  g.la.rec = s->rec.as<CopyRec>(); g.la.out = s->outbuf.as<int64_t>();
+  HostInfo* dev_info = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&dev_info, (void*)s->host_info, 0));
+  g.la.host = dev_info;
   g.la.B = B; g.la.N = N; g.la.D = D; g.la.Ls = Ls; g.la.max_len = max_len; g.la.pad = p->pad_token; g.la.bos = p->bos_token;
   g.la.eos = p->eos_token;
   g.kc.st = s->state.as<DecState>(); g.kc.rec = s->rec.as<CopyRec>(); g.kc.qkv = s->qkv.as<float>();
@@ -791,41 +841,92 @@ static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, 
   g.kc.cache_seq_stride = (long long)g.k.Lc * d; g.kc.cache_layer_stride = (long long)B * g.k.Lc * d;
   g.kc.N = N; g.kc.D1 = D1; g.kc.d = d;
 
-  *s->host_flag = 0;
+  s->host_info->stop = 0;
+  s->host_info->steps_done = 0;
+  s->host_info->width = 1;
   hipLaunchKernelGGL(k_loop_init, dim3(64), dim3(256), 0, st, g.la);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_b, st));
+  j.phase = 1;
+  return TTX_OK;
+}
 
-  // Host loop: at most `max_len` verify steps can ever be needed (every step appends >= 1 token).
-  int launched = 0;
-  for (;;) {
-    HIP_TRY(hipStreamSynchronize(st));
-    if (*s->host_flag) break;
-    if (launched > max_len + 2) return fail(TTX_ERR_HIP, "greedy-speculative loop failed to terminate");
-    TTX_TRY(run_step(s, st, g.k));
-    TTX_TRY(launch_accept_and_commit(s, st, g, greedy));
-    ++launched;
+// Enqueue one verify step: replay the captured graph for this (shape, key-capacity bucket), capturing it on
+// first use.  `width_bound` bounds the reference's generated width when the step runs.
+static int gen_launch_step(GenJob& j, int width_bound) {
+  ttx_session* s = j.s;
+  const StepCtx& k = j.g.k;
+  // prefix keys this step can see: < width_bound; bucket the LDS images of the self-attention in steps of 64 keys
+  int kcap = std::min(k.max_len, ((std::max(width_bound, 1) + 63) / 64) * 64);
+  const bool use_graph = s->use_graphs && !s->profile;
+  if (!use_graph) {
+    TTX_TRY(run_step(s, j.st, k, kcap));
+    TTX_TRY(launch_accept_and_commit(s, j.st, j.g, j.greedy));
+    ++j.launched;
+    return TTX_OK;
   }
-  if (greedy) {
-    hipLaunchKernelGGL(k_gen_to_out, dim3(cdiv(B * max_len, 256)), dim3(256), 0, st, s->gen.as<int>(), g.k.gen_ld, d_out, B, max_len);
+  GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, j.greedy ? 1 : 0, kcap};
+  auto it = s->graphs.find(key);
+  if (it == s->graphs.end()) {
+    if (!s->warmed.count(key)) {
+      // first use of a shape runs eagerly once: function attributes (dynamic LDS limits) are set outside capture
+      s->warmed.insert(key);
+      TTX_TRY(run_step(s, j.st, k, kcap));
+      TTX_TRY(launch_accept_and_commit(s, j.st, j.g, j.greedy));
+      ++j.launched;
+      return TTX_OK;
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipStreamBeginCapture(j.st, hipStreamCaptureModeThreadLocal));
+    int rc = run_step(s, j.st, k, kcap);
+    if (rc == TTX_OK) rc = launch_accept_and_commit(s, j.st, j.g, j.greedy);
+    hipError_t e = hipStreamEndCapture(j.st, &graph);
+    if (rc != TTX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(TTX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(TTX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    if (s->graphs.size() > 512) s->drop_graphs();
+    it = s->graphs.emplace(key, exec).first;
+  }
+  HIP_TRY(hipGraphLaunch(it->second, j.st));
+  ++j.launched;
+  return TTX_OK;
+}
+
+static int gen_finish_enqueue(GenJob& j) {
+  ttx_session* s = j.s;
+  const StepCtx& k = j.g.k;
+  if (j.greedy) {
+    hipLaunchKernelGGL(k_gen_to_out, dim3(cdiv(k.B * k.max_len, 256)), dim3(256), 0, j.st, s->gen.as<int>(), k.gen_ld, j.d_out,
+                       k.B, k.max_len);
     HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemcpyAsync(j.d_out, s->outbuf.as<int64_t>(), (size_t)k.B * k.max_len * 8, hipMemcpyDeviceToDevice, j.st));
   }
-  HIP_TRY(hipEventRecord(s->ev_c, st));
-  HIP_TRY(hipMemcpyAsync(s->host_state, s->state.as<DecState>(), sizeof(DecState), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventRecord(s->ev_c, j.st));
+  HIP_TRY(hipMemcpyAsync(s->host_state, s->state.as<DecState>(), sizeof(DecState), hipMemcpyDeviceToHost, j.st));
+  HIP_TRY(hipEventRecord(s->ev_done, j.st));
+  j.phase = 2;
+  return TTX_OK;
+}
+
+static int gen_finish_collect(GenJob& j) {
+  ttx_session* s = j.s;
   const DecState& hs = *s->host_state;
-  if (stats) {
-    stats->model_calls = hs.steps;
-    stats->accepted_tokens = hs.accepted;
-    stats->produced_tokens = hs.produced;
-    stats->verified_positions = hs.verified_positions;
-    stats->kv_prefix_positions = hs.kv_prefix_positions;
-    stats->src_positions = hs.src_positions;
+  if (j.stats) {
+    j.stats->model_calls = hs.steps;
+    j.stats->accepted_tokens = hs.accepted;
+    j.stats->produced_tokens = hs.produced;
+    j.stats->verified_positions = hs.verified_positions;
+    j.stats->kv_prefix_positions = hs.kv_prefix_positions;
+    j.stats->src_positions = hs.src_positions;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_a, s->ev_b));
-    stats->encode_ms = ms;
+    j.stats->encode_ms = ms;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_b, s->ev_c));
-    stats->decode_ms = ms;
+    j.stats->decode_ms = ms;
   }
   if (s->profile) {
     s->prof_ms = 0;
@@ -835,8 +936,43 @@ static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, 
       if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) s->prof_ms += ms;
     }
   }
+  j.phase = 0;
   if (hs.error) return fail(TTX_ERR_REFERENCE, "a row finished at a width beyond max_len: shape mismatch in the reference (speculative_decoding.py:158)");
   return TTX_OK;
+}
+
+static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p, int64_t* d_out,
+                           ttx_gen_stats* stats, void* stream, bool greedy) {
+  TTX_TRY(gen_validate(s, d_src, B, Ls, p, d_out, greedy));
+  HIP_TRY(hipSetDevice(s->m->device));
+  // The loop runs on the session's own stream (the caller's may be the legacy null stream, which cannot be
+  // captured into a graph); it first waits for the caller's stream, and the call returns only after the
+  // session stream has drained, so the outputs are visible to whatever the caller enqueues next.
+  if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventRecord(s->ev_done, (hipStream_t)stream));
+  HIP_TRY(hipStreamWaitEvent(s->own_stream, s->ev_done, 0));
+  hipStream_t st = s->own_stream;
+  GenJob j;
+  TTX_TRY(gen_start(j, s, st, d_src, B, Ls, p, d_out, stats, greedy));
+  const int D1 = j.g.k.D + 1;
+  // One step in flight: the next step is enqueued as soon as the accept kernel has published the previous one's
+  // result to the host-mapped words (no stream synchronisation inside the loop).
+  volatile HostInfo* hi = s->host_info;
+  HIP_TRY(hipStreamSynchronize(st));            // loop init published (also covers max_len <= 1: stop already set)
+  while (!hi->stop) {
+    if (j.launched > p->max_len + 2) return fail(TTX_ERR_HIP, "decode loop failed to terminate");
+    TTX_TRY(gen_launch_step(j, hi->width + D1));
+    const int want = j.launched;
+    unsigned spins = 0;
+    while (hi->steps_done < want && !hi->stop) {
+      if ((++spins & 0xfff) == 0 && hipStreamQuery(st) == hipSuccess && hi->steps_done < want && !hi->stop)
+        return fail(TTX_ERR_HIP, "verify step finished without publishing its result");
+      __builtin_ia32_pause();
+    }
+  }
+  TTX_TRY(gen_finish_enqueue(j));
+  HIP_TRY(hipStreamSynchronize(st));
+  return gen_finish_collect(j);
 }
 
 extern "C" int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_src, int B, int Ls,
@@ -848,6 +984,75 @@ extern "C" int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_
 extern "C" int ttx_greedy_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p,
                                    int64_t* d_out, ttx_gen_stats* stats, void* stream) {
   return generate_common(s, d_src, B, Ls, p, d_out, stats, stream, true);
+}
+
+// Several batches in flight on one GPU: batch i is decoded on session i % n_sessions, each
+// session on its own stream; one host thread round-robins over the sessions, enqueueing the next verify step of
+// whichever session has published its previous one.  Outputs per batch are identical to the one-at-a-time call.
+extern "C" int ttx_greedy_speculative_generate_many(ttx_session** sessions, int n_sessions, int n_batches,
+                                                    const int64_t* const* d_src, const int* B, const int* Ls,
+                                                    const ttx_gen_params* p, int64_t* const* d_out, ttx_gen_stats* stats,
+                                                    void* stream) {
+  if (!sessions || n_sessions <= 0 || n_batches < 0 || !d_src || !B || !Ls || !p || !d_out)
+    return fail(TTX_ERR_INVALID, "bad argument to ttx_greedy_speculative_generate_many");
+  for (int i = 0; i < n_batches; ++i) TTX_TRY(gen_validate(sessions[0], d_src[i], B[i], Ls[i], p, d_out[i], false));
+  HIP_TRY(hipSetDevice(sessions[0]->m->device));
+  hipStream_t caller = (hipStream_t)stream;
+  // inputs were produced on the caller's stream: every session stream waits for it once
+  hipEvent_t ready;
+  HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ready, caller));
+  std::vector<GenJob> jobs(n_sessions);
+  for (int i = 0; i < n_sessions; ++i) {
+    if (!sessions[i]->own_stream) HIP_TRY(hipStreamCreateWithFlags(&sessions[i]->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamWaitEvent(sessions[i]->own_stream, ready, 0));
+  }
+  const int D1 = p->draft_len + 1;
+  int next = 0, done = 0, rc_final = TTX_OK;
+  while (done < n_batches) {
+    bool progressed = false;
+    for (int i = 0; i < n_sessions; ++i) {
+      GenJob& j = jobs[i];
+      ttx_session* s = sessions[i];
+      if (j.phase == 0) {
+        if (next < n_batches) {
+          j.batch = next++;
+          int rc = gen_start(j, s, s->own_stream, d_src[j.batch], B[j.batch], Ls[j.batch], p, d_out[j.batch],
+                             stats ? &stats[j.batch] : nullptr, false);
+          if (rc != TTX_OK) { rc_final = rc; done = n_batches; break; }
+          progressed = true;
+        }
+        continue;
+      }
+      volatile HostInfo* hi = s->host_info;
+      if (j.phase == 1) {
+        if (hi->stop) {
+          // stop is published by the accept kernel (or by loop init): nothing further to enqueue
+          if (j.launched == 0 && hipStreamQuery(s->own_stream) != hipSuccess) continue;   // init not yet run
+          int rc = gen_finish_enqueue(j);
+          if (rc != TTX_OK) { rc_final = rc; done = n_batches; break; }
+          progressed = true;
+        } else if (hi->steps_done >= j.launched && (j.launched > 0 || hipStreamQuery(s->own_stream) == hipSuccess)) {
+          if (j.launched > p->max_len + 2) { rc_final = fail(TTX_ERR_HIP, "decode loop failed to terminate"); done = n_batches; break; }
+          int rc = gen_launch_step(j, hi->width + D1);
+          if (rc != TTX_OK) { rc_final = rc; done = n_batches; break; }
+          progressed = true;
+        }
+      } else if (j.phase == 2) {
+        if (hipEventQuery(s->ev_done) == hipSuccess) {
+          int rc = gen_finish_collect(j);
+          if (rc != TTX_OK && rc_final == TTX_OK) rc_final = rc;
+          ++done;
+          progressed = true;
+        }
+      }
+    }
+    if (!progressed) __builtin_ia32_pause();
+  }
+  for (int i = 0; i < n_sessions; ++i) (void)hipStreamSynchronize(sessions[i]->own_stream);
+  // later work on the caller's stream must see the outputs
+  (void)hipEventDestroy(ready);
+  return rc_final;
 }
 
 extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches) {

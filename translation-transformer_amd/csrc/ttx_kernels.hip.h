@@ -37,6 +37,10 @@ struct DecState {
 
 struct CopyRec { int b, best, nacc, front_old; };
 
+// Host-mapped (pinned) words the accept kernels publish after every step; the host polls them instead of
+// synchronising the stream.
+struct HostInfo { int stop; int steps_done; int width; int pad_; };
+
 // ------------------------------------------------------------------------------------------------
 // GEMM:  Y[m, n] = sum_k X[m, k] * W[n, k]   (torch.nn.Linear layout: both operands K-contiguous)
 struct GemmArgs {
@@ -941,7 +945,7 @@ __global__ __launch_bounds__(64) void k_make_drafts(const int* src, int src_ld, 
 struct LoopArgs {
   DecState* st; int* act_idx; int* front; int* gen; int gen_ld;
   const int* drafts; const int* pred;
-  CopyRec* rec; int64_t* out; int* host_flag;
+  CopyRec* rec; int64_t* out; HostInfo* host;
   int B, N, D, Ls, max_len, pad, bos, eos;
 };
 
@@ -959,7 +963,10 @@ __global__ void k_loop_init(LoopArgs a) {
     if (s.stop) { s.n_active = 0; s.r_rows = 0; s.m_rows = 0; }
     s.accepted = s.produced = s.verified_positions = s.kv_prefix_positions = s.src_positions = 0;
     *a.st = s;
-    *a.host_flag = s.stop;
+    a.host->width = 1;
+    a.host->steps_done = 0;
+    a.host->stop = s.stop;
+    __threadfence_system();
   }
 }
 
@@ -1037,7 +1044,9 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     st->n_active = stop ? 0 : nn;
     st->r_rows = stop ? 0 : nn * a.N;
     st->m_rows = stop ? 0 : nn * a.N * D1;
-    *a.host_flag = stop;
+    a.host->width = width;
+    a.host->steps_done = st->steps;
+    a.host->stop = stop;
     __threadfence_system();
   }
 }
@@ -1072,7 +1081,9 @@ __global__ __launch_bounds__(256) void k_greedy_accept(LoopArgs a) {
     const int stop = (!s_running || f + 1 >= a.max_len - 1) ? 1 : 0;
     st->stop = stop;
     if (stop) { st->n_active = 0; st->r_rows = 0; st->m_rows = 0; }
-    *a.host_flag = stop;
+    a.host->width = f + 2;
+    a.host->steps_done = st->steps;
+    a.host->stop = stop;
     __threadfence_system();
   }
 }

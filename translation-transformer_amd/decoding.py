@@ -61,6 +61,37 @@ class TranslationInferenceGreedySpeculative:
         self.last_stats = st
         return out
 
+    def generate_many(self, batches: list, in_flight: int = 4) -> list:
+        """Decode several batches with up to `in_flight` of them on the GPU at once (one session + stream each;
+        ttx_greedy_speculative_generate_many).  Returns one [B,1,max_len] tensor per batch, each identical to what
+        ``generate`` returns for that batch; counters accumulate as if ``generate`` had been called per batch."""
+        m = self.model
+        if not batches:
+            return []
+        srcs = [b.to(m.device, torch.int64).contiguous() for b in batches]
+        outs = [torch.empty((s.shape[0], 1, self.max_len), dtype=torch.int64, device=m.device) for s in srcs]
+        n = len(srcs)
+        pool = m.session_pool(max(1, min(in_flight, n)))
+        sess = (C.c_void_p * len(pool))(*[p.value for p in pool])
+        src_p = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        out_p = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        Bs = (C.c_int * n)(*[s.shape[0] for s in srcs])
+        Ls = (C.c_int * n)(*[s.shape[1] for s in srcs])
+        p = N.GenParams(self.max_len, self.draft_len, self.n_drafts, self.pad_token, self.bos_token, self.eos_token,
+                        self.replace_token, 0)
+        stats = (N.GenStats * n)()
+        N.check(m._lib.ttx_greedy_speculative_generate_many(sess, len(pool), n, src_p, Bs, Ls, C.byref(p), out_p, stats,
+                                                            m._stream()))
+        t = self.stats_total
+        for i, st in enumerate(stats):
+            self.model_calls_num += int(st.model_calls)
+            for k in ("accepted_tokens", "produced_tokens", "verified_positions", "kv_prefix_positions", "src_positions",
+                      "encode_ms", "decode_ms"):
+                t[k] += getattr(st, k)
+            t["src_tokens_padded"] += srcs[i].shape[0] * srcs[i].shape[1]
+            t["batches"] += 1
+        return outs
+
 
 # =====================================================================================================
 # Beam paths.  The model forward (encoder, full-prefix decoder, classifier) and the draft maker run in

@@ -82,7 +82,19 @@ class NativeTransformer:
         N.check(self._lib.ttx_session_create(self._model, C.byref(s)))
         return s
 
+    def session_pool(self, n: int) -> list:
+        """`n` sessions (the default one first) for several batches in flight; created once, reused."""
+        pool = getattr(self, "_pool", None)
+        if pool is None:
+            pool = self._pool = [self._session]
+        while len(pool) < n:
+            pool.append(self.new_session())
+        return pool[:n]
+
     def close(self) -> None:
+        for extra in getattr(self, "_pool", [])[1:]:
+            self._lib.ttx_session_destroy(extra)
+        self._pool = None
         if getattr(self, "_session", None):
             self._lib.ttx_session_destroy(self._session)
             self._session = None
