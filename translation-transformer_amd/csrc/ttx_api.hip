@@ -266,7 +266,8 @@ struct ttx_session {
   // full decoder
   Buf tok_tgt, mem_pad_tmp;
   // loop
-  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf;
+  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf, dbg_self, dbg_cross;
+  bool attn_debug = false;
   HostInfo* host_info = nullptr;   // pinned + device-mapped, written by the accept kernels
   hipStream_t own_stream = nullptr; // used by the many-batches driver
   uint64_t alloc_generation = 0;   // bumped whenever a workspace buffer moves (captured graphs hold raw pointers)
@@ -288,7 +289,7 @@ struct ttx_session {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
   ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
-                                 &kcache, &vcache, &src32, &outbuf}) all.push_back(b); }
+                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross}) all.push_back(b); }
 };
 
 static thread_local uint64_t* g_alloc_gen = nullptr;   // alloc_generation of the session being sized
@@ -329,6 +330,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   s->profile = pf && pf[0] == '1';
   s->gemm_v1 = getenv("TTX_GEMM_V1") != nullptr;
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
+  s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
   *out = s;
   return TTX_OK;
 }
@@ -706,6 +708,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     a.tok = s->gen.as<int>(); a.pad = c.pad_token; a.st = dst; a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>();
     a.kcache = s->kcache.as<float>() + (size_t)l * cache_layer; a.vcache = s->vcache.as<float>() + (size_t)l * cache_layer;
     a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D1 = D1;
+    if (s->attn_debug && l == Ld - 1) a.dbg = s->dbg_self.as<unsigned long long>();
     TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, k.B, H, k.N * D1, kcap, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
                     nullptr, x1, m_ptr, Mmax));
@@ -714,6 +717,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     ca.q = q2; ca.ldq = d; ca.k = s->memkv.as<float>() + (size_t)l * 2 * d; ca.v = ca.k + d; ca.ldkv = Ld * 2 * d;
     ca.out = ao; ca.d = d; ca.scale = scale; ca.Lk = k.Ls; ca.key_pad = s->src_valid.as<uint8_t>();
     ca.st = dst; ca.act_idx = s->act_idx.as<int>(); ca.front = s->front.as<int>(); ca.N = k.N; ca.D1 = D1;
+    if (s->attn_debug && l == Ld - 1) ca.dbg = s->dbg_cross.as<unsigned long long>();
     TTX_TRY(launch_attn<ATT_STEP_CROSS>(s, st, ca, k.B, H, k.N * D1, k.Ls, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
                     nullptr, x2, m_ptr, Mmax));
@@ -805,6 +809,12 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   TTX_TRY(ensure(s->state, sizeof(DecState), st));
   TTX_TRY(ensure(s->logits, Mmax * V * 4, st));
   TTX_TRY(ensure(s->outbuf, (size_t)B * max_len * 8, st));
+  if (s->attn_debug) {
+    TTX_TRY(ensure(s->dbg_self, (size_t)B * c.num_heads * 8 * 8, st));
+    TTX_TRY(ensure(s->dbg_cross, (size_t)B * c.num_heads * 8 * 8, st));
+    HIP_TRY(hipMemsetAsync(s->dbg_self.p, 0, (size_t)B * c.num_heads * 64, st));
+    HIP_TRY(hipMemsetAsync(s->dbg_cross.p, 0, (size_t)B * c.num_heads * 64, st));
+  }
   TTX_TRY(ensure(s->kcache, (size_t)Ld * B * g.k.Lc * d * 4, st));
   TTX_TRY(ensure(s->vcache, (size_t)Ld * B * g.k.Lc * d * 4, st));
   // the encoder and the step share the activation buffers; size them for the larger of the two
@@ -934,6 +944,27 @@ static int gen_finish_collect(GenJob& j) {
     for (size_t i = 0; i < s->ev_used; ++i) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) s->prof_ms += ms;
+    }
+  }
+  if (s->attn_debug) {
+    // diagnostic: phase durations (us) of the LAST step's last-layer attention launches, averaged over the
+    // workgroups that ran (stamps: 0 start, 1 staged, 2 QK, 3 softmax, 4 PV, 5 stored (tile 0), 6 end)
+    const int nb = j.g.k.B * s->m->cfg.num_heads;
+    std::vector<unsigned long long> h((size_t)nb * 8);
+    for (int which = 0; which < 2; ++which) {
+      Buf& b = which ? s->dbg_cross : s->dbg_self;
+      if (hipMemcpy(h.data(), b.p, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+      double acc[6] = {0, 0, 0, 0, 0, 0};
+      int n = 0;
+      for (int i = 0; i < nb; ++i) {
+        const unsigned long long* q = &h[(size_t)i * 8];
+        if (!q[0] || !q[6]) continue;
+        for (int ph = 0; ph < 6; ++ph) acc[ph] += (double)(q[ph + 1] - q[ph]) * 0.01;
+        ++n;
+      }
+      if (n)
+        fprintf(stderr, "[ttx attn debug] %s blocks=%d stage=%.2f qk=%.2f softmax=%.2f pv=%.2f store=%.2f tile1=%.2f us\n",
+                which ? "cross" : "self", n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n);
     }
   }
   j.phase = 0;

@@ -473,6 +473,7 @@ struct AttnArgs {
   const DecState* st; const int* act_idx; const int* front;
   const float* kcache; const float* vcache; long long cache_seq_stride;  // floats per sequence in the cache
   int gen_ld; int N; int D1;
+  unsigned long long* dbg;         // diagnostic builds only: per-block phase stamps (100 MHz realtime clock)
 };
 
 template <int MODE>
@@ -560,54 +561,58 @@ __global__ __launch_bounds__(64) void k_attn(AttnArgs a) {
 // and over the encoder memory.  K and V of every visible key are staged in LDS by coalesced 128-B row
 // loads issued back to back (one latency, not one per key chunk); S = Q·Kᵀ and O = P·V run on the fp32
 // MFMA (32x32x2), key tiles / key ranges split over the 4 waves; softmax by wavefront shuffles.
-constexpr int A2_QT = 32;                  // queries per tile
+constexpr int A2_MT = 32;                  // rows of one MFMA tile
+constexpr int A2_QT = 64;                  // queries per workgroup (two MFMA row tiles share the staged K/V)
 constexpr int A2_LDQ = ATT_DH + 4;         // LDS row stride of Q and K rows (conflict-free ds_read_b128)
 
 __host__ __device__ inline int a2_nkp(int nk) { return (nk + 31) & ~31; }
 __host__ __device__ inline size_t attn2_lds_bytes(int max_keys) {
   const size_t nkp = a2_nkp(max_keys);
-  return sizeof(float) * ((size_t)A2_QT * A2_LDQ + nkp * A2_LDQ + nkp * ATT_DH + (size_t)A2_QT * (nkp + 4) + A2_QT +
-                          (size_t)4 * A2_QT * 33) +
+  return sizeof(float) * ((size_t)A2_QT * A2_LDQ + nkp * A2_LDQ + nkp * ATT_DH + (size_t)A2_MT * (nkp + 4) + A2_MT +
+                          (size_t)4 * A2_MT * 33) +
          sizeof(int) * (nkp + A2_QT);
 }
 
 // Visibility is decided from one int per key and one per query, computed once while staging:
-//   key flag  < 0        masked (PAD key / padding row)
-//   key flag == A2_ALL   visible to every query (cached prefix, encoder memory)
-//   otherwise (group << 16 | position): visible to queries of the same group at position >= key position
+//   key flag A2_MASKED   masked (PAD key / padding row)
+//   key flag A2_ALL      visible to every query (cached prefix, encoder memory)
+//   otherwise a2_flag(group, position): visible to queries of the same group at position >= key position.
+// Groups are spaced 2^17 apart and positions are < 2^16, so "same group and kpos <= qpos" is the single unsigned
+// comparison (qf - kf) < 2^16.
 constexpr int A2_ALL = 0x7fffffff;
+constexpr int A2_MASKED = 0x7ffffffe;
+__host__ __device__ inline int a2_flag(int group, int pos) { return (group << 17) | pos; }
 __device__ __forceinline__ bool a2_visible(int qf, int kf) {
-  return kf >= 0 && (kf == A2_ALL || ((kf >> 16) == (qf >> 16) && (kf & 0xffff) <= (qf & 0xffff)));
+  return kf == A2_ALL || (unsigned)(qf - kf) < 65536u;
 }
 
 // keyptr(key, kp, vp): branch-free K/V row pointers of key (0 <= key < nk); keyflag(key), qflag(qi): see above.
 template <class KeyPtr, class KeyFlag, class QFlag>
 __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq, int nq, int nk, KeyPtr keyptr, KeyFlag keyflag,
-                                           QFlag qflag, float* __restrict__ out, int ldo, float scale, float* lds) {
+                                           QFlag qflag, float* __restrict__ out, int ldo, float scale, float* lds,
+                                           unsigned long long* dbg = nullptr) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
   const int nkp = a2_nkp(nk);
+#define TTX_STAMP(i) do { if (dbg && t == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  TTX_STAMP(0);
   const int lds_s = nkp + 4;
-  float* Qs = lds;                                   // [32][36]
+  float* Qs = lds;                                   // [64][36]
   float* Ks = Qs + A2_QT * A2_LDQ;                   // [nkp][36]
   float* Vs = Ks + (size_t)nkp * A2_LDQ;             // [nkp][32]
-  float* S = Vs + (size_t)nkp * ATT_DH;              // [32][nkp+4]
-  float* inv = S + (size_t)A2_QT * lds_s;            // [32]
-  float* Op = inv + A2_QT;                           // [4 waves][32][33] partial outputs
-  int* kfl = reinterpret_cast<int*>(Op + 4 * A2_QT * 33);   // [nkp]
-  int* qfl = kfl + nkp;                              // [32]
+  float* S = Vs + (size_t)nkp * ATT_DH;              // [32][nkp+4]   scores of the current row tile
+  float* inv = S + (size_t)A2_MT * lds_s;            // [32]
+  float* Op = inv + A2_MT;                           // [4 waves][32][33] partial outputs
+  int* kfl = reinterpret_cast<int*>(Op + 4 * A2_MT * 33);   // [nkp]
+  int* qfl = kfl + nkp;                              // [64]
 
-  // ---- flags first (their token loads overlap the K/V traffic below)
-  for (int key = t; key < nkp; key += 256) kfl[key] = (key < nk) ? keyflag(key) : -1;
-  if (t < A2_QT) qfl[t] = qflag(t);
-
-  // ---- stage Q, K, V: a row is 32 floats = 8 lanes x float4.  Loads are unconditional (indices are
-  // clamped; rows past nq / nk are masked through the flags), so every pass's requests go out back to
-  // back instead of one drained pass at a time.
+  // ---- stage Q, K, V: a row is 32 floats = 8 lanes x float4.  Loads are unconditional (indices are clamped;
+  // rows past nq / nk are masked through the flags) and all of them are requested before the first LDS write.
   const int lr = t >> 3, lc = (t & 7) * 4;
-  const float4 qv = *reinterpret_cast<const float4*>(q + (size_t)min(lr, nq - 1) * ldq + lc);
-  constexpr int A2_U = 8;                            // passes (of 32 keys) requested before the first LDS write
   typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 qv0 = *reinterpret_cast<const f32x4*>(q + (size_t)min(lr, nq - 1) * ldq + lc);
+  f32x4 qv1 = *reinterpret_cast<const f32x4*>(q + (size_t)min(lr + 32, nq - 1) * ldq + lc);
+  constexpr int A2_U = 8;                            // passes of 32 keys in flight
   for (int k0 = 0; k0 < nkp; k0 += 32 * A2_U) {
     f32x4 kv[A2_U], vv[A2_U];
 #pragma unroll
@@ -617,6 +622,10 @@ __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq,
       keyptr(min(k0 + u * 32 + lr, nk - 1), kp, vp);
       kv[u] = *reinterpret_cast<const f32x4*>(kp + lc);
       vv[u] = *reinterpret_cast<const f32x4*>(vp + lc);
+    }
+    if (k0 == 0) {   // the visibility flags' token loads ride behind the K/V requests
+      for (int key = t; key < nkp; key += 256) kfl[key] = (key < nk) ? keyflag(key) : A2_MASKED;
+      if (t < A2_QT) qfl[t] = qflag(t);
     }
     // every request is in flight before the first value is consumed: the empty asm reads all sixteen
     // registers, so the scheduler cannot sink a load down to its LDS write
@@ -631,83 +640,103 @@ __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq,
       }
     }
   }
-  *reinterpret_cast<float4*>(&Qs[lr * A2_LDQ + lc]) = qv;
+  *reinterpret_cast<f32x4*>(&Qs[lr * A2_LDQ + lc]) = qv0;
+  *reinterpret_cast<f32x4*>(&Qs[(lr + 32) * A2_LDQ + lc]) = qv1;
   __syncthreads();
+  TTX_STAMP(1);
 
-  // ---- S = scale * Q Kᵀ with masking; wave w takes key tiles w, w+4, ...
-  for (int kt = wave; kt * 32 < nkp; kt += 4) {
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const float* ap = &Qs[r * A2_LDQ + 4 * h];
-    const float* bp = &Ks[(size_t)(kt * 32 + r) * A2_LDQ + 4 * h];
-#pragma unroll
-    for (int kk = 0; kk < ATT_DH; kk += 8) {
-      const float4 av = *reinterpret_cast<const float4*>(ap + kk);
-      const float4 bv = *reinterpret_cast<const float4*>(bp + kk);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
-    }
-    const int key = kt * 32 + r;
-    const int kf = kfl[key];
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int qi = (v & 3) + 8 * (v >> 2) + 4 * h;
-      const bool ok = (qi < nq) && a2_visible(qfl[qi], kf);
-      S[(size_t)qi * lds_s + key] = ok ? acc[v] * scale : -INFINITY;
-    }
-  }
-  __syncthreads();
+  const int n_mt = (nq + A2_MT - 1) / A2_MT;         // 1 or 2 row tiles
 
-  // ---- softmax: wave w owns queries 8w..8w+7
-  for (int qi = wave * 8; qi < wave * 8 + 8; ++qi) {
-    float* row = S + (size_t)qi * lds_s;
-    float m = -INFINITY;
-    for (int key = lane; key < nkp; key += 64) m = fmaxf(m, row[key]);
-    m = wave_max(m);
-    float sum = 0.f;
-    for (int key = lane; key < nkp; key += 64) {
-      const float s = row[key];
-      const float p = (s == -INFINITY) ? 0.f : expf(s - m);
-      row[key] = p;
-      sum += p;
+  // The two row tiles (queries 0-31, 32-63) run one after the other through the same score buffer: K and V
+  // stay staged, the S image is reused.
+  const int n_kt = nkp / 32;
+  for (int mt = 0; mt < n_mt; ++mt) {
+    const int q0 = mt * A2_MT;
+    // ---- S = scale * Q Kᵀ with masking; key tiles are dealt to the 4 waves
+    for (int kt = wave; kt < n_kt; kt += 4) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = &Qs[(q0 + r) * A2_LDQ + 4 * h];
+      const float* bp = &Ks[(size_t)(kt * 32 + r) * A2_LDQ + 4 * h];
+#pragma unroll
+      for (int kk = 0; kk < ATT_DH; kk += 8) {
+        const float4 av = *reinterpret_cast<const float4*>(ap + kk);
+        const float4 bv = *reinterpret_cast<const float4*>(bp + kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+      }
+      const int key = kt * 32 + r;
+      const int kf = kfl[key];
+      const int* qf = qfl + q0 + 4 * h;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int dq = (v & 3) + 8 * (v >> 2);        // rows past nq carry a query flag that sees nothing but A2_ALL
+        S[(size_t)(dq + 4 * h) * lds_s + key] = a2_visible(qf[dq], kf) ? acc[v] * scale : -INFINITY;
+      }
     }
-    sum = wave_sum(sum);
-    if (lane == 0) inv[qi] = sum > 0.f ? 1.0f / sum : 0.f;
-  }
-  __syncthreads();
+    __syncthreads();
+    if (mt == 0) TTX_STAMP(2);
 
-  // ---- O = P V: wave w takes keys [w*nkp/4, (w+1)*nkp/4)
-  {
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int kq = nkp / 4;
-    const float* prow = S + (size_t)r * lds_s + 4 * h;
-    for (int kb = wave * kq; kb < (wave + 1) * kq; kb += 8) {
-      const float4 pv = *reinterpret_cast<const float4*>(prow + kb);
-      const float* vb = Vs + (size_t)(kb + 4 * h) * ATT_DH + r;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.x, vb[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.y, vb[ATT_DH], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.z, vb[2 * ATT_DH], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.w, vb[3 * ATT_DH], acc, 0, 0, 0);
+    // ---- softmax: every wave owns 8 query rows, 8 lanes per row (each lane nkp/8 keys, 3-step shuffles).
+    // Rows past nq hold finite or -inf scores of no consequence: their outputs are never stored.
+    {
+      const int ql = wave * 8 + (lane >> 3), l8 = lane & 7;
+      float* row = S + (size_t)ql * lds_s;
+      float m = -INFINITY;
+      for (int key = l8; key < nkp; key += 8) m = fmaxf(m, row[key]);
+      m = fmaxf(m, __shfl_xor(m, 4, 8));
+      m = fmaxf(m, __shfl_xor(m, 2, 8));
+      m = fmaxf(m, __shfl_xor(m, 1, 8));
+      const float mm = (m == -INFINITY) ? 0.f : m;   // fully masked row: every p becomes exp(-inf) = 0
+      float sum = 0.f;
+      for (int key = l8; key < nkp; key += 8) {
+        const float p = __expf(row[key] - mm);
+        row[key] = p;
+        sum += p;
+      }
+      sum += __shfl_xor(sum, 4, 8);
+      sum += __shfl_xor(sum, 2, 8);
+      sum += __shfl_xor(sum, 1, 8);
+      if (l8 == 0) inv[ql] = sum > 0.f ? 1.0f / sum : 0.f;
     }
-    float* part = Op + (size_t)wave * (A2_QT * 33);
+    __syncthreads();
+    if (mt == 0) TTX_STAMP(3);
+
+    // ---- O = P V: wave w takes keys [w*nkp/4, (w+1)*nkp/4), partial sums meet in LDS
+    {
+      f32x16 acc;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int qi = (v & 3) + 8 * (v >> 2) + 4 * h;
-      part[qi * 33 + r] = acc[v];
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const int kq = nkp / 4;
+      const float* prow = S + (size_t)r * lds_s + 4 * h;
+      for (int kb = wave * kq; kb < (wave + 1) * kq; kb += 8) {
+        const float4 pv = *reinterpret_cast<const float4*>(prow + kb);
+        const float* vb = Vs + (size_t)(kb + 4 * h) * ATT_DH + r;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.x, vb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.y, vb[ATT_DH], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.z, vb[2 * ATT_DH], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.w, vb[3 * ATT_DH], acc, 0, 0, 0);
+      }
+      float* part = Op + (size_t)wave * (A2_MT * 33);
+#pragma unroll
+      for (int v = 0; v < 16; ++v) part[((v & 3) + 8 * (v >> 2) + 4 * h) * 33 + r] = acc[v];
     }
+    __syncthreads();
+    if (mt == 0) TTX_STAMP(4);
+    for (int e = t; e < A2_MT * ATT_DH; e += 256) {
+      const int ql = e >> 5, c = e & 31;
+      const float o = Op[ql * 33 + c] + Op[A2_MT * 33 + ql * 33 + c] + Op[2 * A2_MT * 33 + ql * 33 + c] +
+                      Op[3 * A2_MT * 33 + ql * 33 + c];
+      if (q0 + ql < nq) out[(size_t)(q0 + ql) * ldo + c] = o * inv[ql];
+    }
+    if (mt == 0) TTX_STAMP(5);
+    if (mt + 1 < n_mt) __syncthreads();               // S, inv and Op are rewritten by the next row tile
   }
-  __syncthreads();
-  for (int e = t; e < A2_QT * ATT_DH; e += 256) {
-    const int qi = e >> 5, c = e & 31;
-    const float o = Op[qi * 33 + c] + Op[A2_QT * 33 + qi * 33 + c] + Op[2 * A2_QT * 33 + qi * 33 + c] +
-                    Op[3 * A2_QT * 33 + qi * 33 + c];
-    if (qi < nq) out[(size_t)qi * ldo + c] = o * inv[qi];
-  }
+  TTX_STAMP(6);
+#undef TTX_STAMP
 }
 
 // amdgpu_waves_per_eu(1, 2): the LDS images allow at most two workgroups per CU, so let the compiler keep the
@@ -733,7 +762,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       const int ld = a.ldkv;
       attn2_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, a.L,
                  [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
-                 [=](int key) { return tk[key] != pad ? A2_ALL : -1; }, q_any,
+                 [=](int key) { return tk[key] != pad ? A2_ALL : A2_MASKED; }, q_any,
                  a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
     } else {
       const int mr = a.mem_row ? a.mem_row[g] : g;
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       const int ld = a.ldkv;
       attn2_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, a.Lk,
                  [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
-                 [=](int key) { return kpad[key] == 0 ? A2_ALL : -1; }, q_any,
+                 [=](int key) { return kpad[key] == 0 ? A2_ALL : A2_MASKED; }, q_any,
                  a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
     }
   } else if constexpr (MODE == ATT_FULL_SELF) {
@@ -760,8 +789,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int ld = a.ldkv;
     attn2_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, min(a.L, q0 + nq),
                [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
-               [=](int key) { return tk[key] != pad ? key : -1; },       // group 0, position = key
-               [=](int qi) { return q0 + qi; },
+               [=](int key) { return tk[key] != pad ? a2_flag(0, key) : A2_MASKED; },
+               [=](int qi) { return a2_flag(0, q0 + qi); },
                a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
   } else {
     // step modes: group = running sequence (slot); a tile holds whole drafts when D+1 <= 32
@@ -804,14 +833,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                    vp = (cached ? vc : vb) + off;
                  },
                  [=](int key) {
-                   if (key < f) return tk[key] != pad ? A2_ALL : -1;
+                   if (key < f) return tk[key] != pad ? A2_ALL : A2_MASKED;
                    const int kj = key - f;                     // row inside the tile's drafts
                    const int kd = kj / D1, kp = kj - kd * D1;
-                   if (kp == 0 && tk[f] == pad) return -1;     // the front token itself is a PAD key
-                   return (kd << 16) | kp;
+                   if (kp == 0 && tk[f] == pad) return A2_MASKED;   // the front token itself is a PAD key
+                   return a2_flag(kd, kp);
                  },
-                 [=](int qi) { const int qd = qi / D1; return (qd << 16) | (j0 + qi - qd * D1); },
-                 a.out + qrow0 * a.d + hd, a.d, a.scale, lds);
+                 [=](int qi) { const int qd = qi / D1; return a2_flag(qd, j0 + qi - qd * D1); },
+                 a.out + qrow0 * a.d + hd, a.d, a.scale, lds,
+                 a.dbg ? a.dbg + 8 * (size_t)(blockIdx.x * gridDim.y + blockIdx.y) : nullptr);
     } else {
       const size_t mrow0 = (size_t)b * a.Lk;
       const uint8_t* kv = a.key_pad + mrow0;
@@ -820,8 +850,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       const int ld = a.ldkv;
       attn2_core(a.q + qrow0 * a.ldq + hd, a.ldq, nq, a.Lk,
                  [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
-                 [=](int key) { return kv[key] != 0 ? A2_ALL : -1; }, q_any,
-                 a.out + qrow0 * a.d + hd, a.d, a.scale, lds);
+                 [=](int key) { return kv[key] != 0 ? A2_ALL : A2_MASKED; }, q_any,
+                 a.out + qrow0 * a.d + hd, a.d, a.scale, lds,
+                 a.dbg ? a.dbg + 8 * (size_t)(blockIdx.x * gridDim.y + blockIdx.y) : nullptr);
     }
   }
 }
