@@ -436,12 +436,14 @@ static int launch_attn(ttx_session* s, hipStream_t st, const AttnArgs& a, int gr
                        int N = 1, int D1 = 1) {
   if (groups <= 0 || q_per_group <= 0) return TTX_OK;
   constexpr bool step = (MODE == ATT_STEP_SELF || MODE == ATT_STEP_CROSS);
-  const int keys2 = (MODE == ATT_STEP_SELF) ? max_keys + std::max(A2_QT, D1) : max_keys;
+  // step modes: q_per_group = RPS = 1 + N*D rows per running sequence.  Self-attention keys of one workgroup:
+  // prefix (< max_keys) + front row + the rows of every draft with a query among its 64 rows.
+  const int D = D1 - 1;
+  const int draft_keys = (D > 0) ? (std::min(N, (A2_QT + D - 2) / D + 1)) * D : 0;
+  const int keys2 = (MODE == ATT_STEP_SELF) ? max_keys + 1 + draft_keys : max_keys;
   const size_t lds2 = attn2_lds_bytes(keys2);
   if (lds2 <= kAttn2LdsLimit && !s->attn_v1) {
-    int tiles;
-    if (step) tiles = (D1 <= A2_QT) ? cdiv(N, A2_QT / D1) : N * cdiv(D1, A2_QT);
-    else tiles = cdiv(q_per_group, A2_QT);
+    const int tiles = cdiv(q_per_group, A2_QT);
     static bool attr_set[8] = {false, false, false, false, false, false, false, false};
     if (lds2 > 64 * 1024 && !attr_set[MODE]) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn2<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -452,20 +454,16 @@ static int launch_attn(ttx_session* s, hipStream_t st, const AttnArgs& a, int gr
     HIP_TRY(hipGetLastError());
     return TTX_OK;
   }
-  const int keys1 = (MODE == ATT_STEP_SELF) ? max_keys + D1 : max_keys;
+  const int keys1 = (MODE == ATT_STEP_SELF) ? max_keys + q_per_group : max_keys;
   const size_t lds = attn_lds_bytes(keys1);
   if (lds > kAttn2LdsLimit) return fail(TTX_ERR_INVALID, "sequence too long for the attention kernels' LDS score buffer");
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int rows = step ? groups * N : groups;
-  const int qn = step ? D1 : q_per_group;
-  hipLaunchKernelGGL((k_attn<MODE>), dim3(rows, H, cdiv(qn, ATT_MAXQ)), dim3(64), lds, st, a);
+  hipLaunchKernelGGL((k_attn<MODE>), dim3(groups, H, cdiv(q_per_group, ATT_MAXQ)), dim3(64), lds, st, a);
   HIP_TRY(hipGetLastError());
   return TTX_OK;
 }
 
-// GEMM with N == d followed by bias + residual + LayerNorm(s): the GEMM writes split-K slabs, the finish
-// kernel reduces them.
 static int gemm_ln(ttx_session* s, hipStream_t st, const float* X, int ldx, int K, const float* W, const float* bias,
                    const float* resid, const float* g1, const float* b1, const float* g2, const float* b2,
                    const uint8_t* row_valid, float* Y, const int* m_ptr, int Mmax) {
@@ -675,7 +673,8 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
   const ttx_config& c = m->cfg;
   const int d = c.embedding_dim, F = c.feedforward_dim, H = c.num_heads, V = c.vocab_size, Ld = c.num_decoder_layers;
   const int D1 = k.D + 1;
-  const int Rmax = k.B * k.N, Mmax = Rmax * D1;
+  const int RPS = step_rps(k.N, k.D);
+  const int Mmax = k.B * RPS;
   DecState* dst = s->state.as<DecState>();
   const int* m_ptr = &dst->m_rows;
   float* x = s->x.as<float>();
@@ -707,18 +706,18 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d; a.scale = scale;
     a.tok = s->gen.as<int>(); a.pad = c.pad_token; a.st = dst; a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>();
     a.kcache = s->kcache.as<float>() + (size_t)l * cache_layer; a.vcache = s->vcache.as<float>() + (size_t)l * cache_layer;
-    a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D1 = D1;
+    a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D = k.D;
     if (s->attn_debug && l == Ld - 1) a.dbg = s->dbg_self.as<unsigned long long>();
-    TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, k.B, H, k.N * D1, kcap, k.N, D1));
+    TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, k.B, H, RPS, kcap, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
                     nullptr, x1, m_ptr, Mmax));
     TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, m_ptr, Mmax, d, d, false, 0, 0));
     AttnArgs ca{};
     ca.q = q2; ca.ldq = d; ca.k = s->memkv.as<float>() + (size_t)l * 2 * d; ca.v = ca.k + d; ca.ldkv = Ld * 2 * d;
     ca.out = ao; ca.d = d; ca.scale = scale; ca.Lk = k.Ls; ca.key_pad = s->src_valid.as<uint8_t>();
-    ca.st = dst; ca.act_idx = s->act_idx.as<int>(); ca.front = s->front.as<int>(); ca.N = k.N; ca.D1 = D1;
+    ca.st = dst; ca.act_idx = s->act_idx.as<int>(); ca.front = s->front.as<int>(); ca.N = k.N; ca.D = k.D;
     if (s->attn_debug && l == Ld - 1) ca.dbg = s->dbg_cross.as<unsigned long long>();
-    TTX_TRY(launch_attn<ATT_STEP_CROSS>(s, st, ca, k.B, H, k.N * D1, k.Ls, k.N, D1));
+    TTX_TRY(launch_attn<ATT_STEP_CROSS>(s, st, ca, k.B, H, RPS, k.Ls, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
                     nullptr, x2, m_ptr, Mmax));
     TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, m_ptr, Mmax, F, d, true, 0, 0));
@@ -792,7 +791,7 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   g.k.B = B; g.k.Ls = Ls; g.k.N = N; g.k.D = D; g.k.max_len = max_len; g.k.p = *p;
   g.k.Lc = max_len + D1;           // cache positions per row (front + D < max_len + D)
   g.k.gen_ld = max_len + D + 2;
-  const size_t Mmax = (size_t)B * N * D1;
+  const size_t Mmax = (size_t)B * step_rps(N, D);
 
   const uint64_t gen_before = s->alloc_generation;
   g_alloc_gen = &s->alloc_generation;
@@ -849,7 +848,7 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   g.kc.qkv_layer_stride = (long long)Mmax * 3 * d;
   g.kc.kcache = s->kcache.as<float>(); g.kc.vcache = s->vcache.as<float>();
   g.kc.cache_seq_stride = (long long)g.k.Lc * d; g.kc.cache_layer_stride = (long long)B * g.k.Lc * d;
-  g.kc.N = N; g.kc.D1 = D1; g.kc.d = d;
+  g.kc.N = N; g.kc.D = D; g.kc.d = d;
 
   s->host_info->stop = 0;
   s->host_info->steps_done = 0;

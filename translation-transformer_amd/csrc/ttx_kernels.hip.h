@@ -372,15 +372,13 @@ __host__ __device__ inline size_t attn_lds_bytes(int max_keys) {
   return sizeof(float) * ((size_t)ATT_MAXQ * ATT_DH + (size_t)max_keys * ATT_SQ + ATT_MAXQ);
 }
 
-template <class VA, class VB>
-__device__ __forceinline__ void attn_core(const float* __restrict__ q, int ldq, int nq,
-                                          const float* __restrict__ kA, const float* __restrict__ vA, int ldA, int nA, VA validA,
-                                          const float* __restrict__ kB, const float* __restrict__ vB, int ldB, int nB, int qpos0, VB validB,
+// keyptr(key, kp, vp): K/V row pointers of key; vis(i, key): may query i (0..nq) see key?
+template <class KeyPtr, class Vis>
+__device__ __forceinline__ void attn_core(const float* __restrict__ q, int ldq, int nq, int nk, KeyPtr keyptr, Vis vis,
                                           float* __restrict__ out, int ldo, float scale, float* lds) {
   const int lane = threadIdx.x & 63;
   float* Qs = lds;                               // [MAXQ][DH]
   float* S = lds + ATT_MAXQ * ATT_DH;            // [nk][SQ]
-  const int nk = nA + nB;
   float* inv = S + (size_t)nk * ATT_SQ;          // [MAXQ]
 
   for (int e = lane * 4; e < nq * ATT_DH; e += 256) {
@@ -394,10 +392,8 @@ __device__ __forceinline__ void attn_core(const float* __restrict__ q, int ldq, 
     const int key = c0 + lane;
     if (key < nk) {
       const float* kp;
-      bool ok;
-      int jb = -1;
-      if (key < nA) { kp = kA + (size_t)key * ldA; ok = validA(key); }
-      else { jb = key - nA; kp = kB + (size_t)jb * ldB; ok = validB(jb); }
+      const float* vp;
+      keyptr(key, kp, vp);
       float4 kr[ATT_DH / 4];
 #pragma unroll
       for (int c = 0; c < ATT_DH / 4; ++c) kr[c] = *reinterpret_cast<const float4*>(kp + 4 * c);
@@ -410,8 +406,7 @@ __device__ __forceinline__ void attn_core(const float* __restrict__ q, int ldq, 
           dot = fmaf(kr[c].x, qq.x, dot); dot = fmaf(kr[c].y, qq.y, dot);
           dot = fmaf(kr[c].z, qq.z, dot); dot = fmaf(kr[c].w, qq.w, dot);
         }
-        const bool vis = ok && (jb < 0 || jb <= qpos0 + i);
-        S[(size_t)key * ATT_SQ + i] = vis ? dot * scale : -INFINITY;
+        S[(size_t)key * ATT_SQ + i] = vis(i, key) ? dot * scale : -INFINITY;
       }
     }
   }
@@ -424,8 +419,8 @@ __device__ __forceinline__ void attn_core(const float* __restrict__ q, int ldq, 
     m = wave_max(m);
     float sum = 0.f;
     for (int key = lane; key < nk; key += 64) {
-      const float s = S[(size_t)key * ATT_SQ + i];
-      const float p = (s == -INFINITY) ? 0.f : expf(s - m);
+      const float sv = S[(size_t)key * ATT_SQ + i];
+      const float p = (sv == -INFINITY) ? 0.f : expf(sv - m);
       S[(size_t)key * ATT_SQ + i] = p;
       sum += p;
     }
@@ -441,7 +436,9 @@ __device__ __forceinline__ void attn_core(const float* __restrict__ q, int ldq, 
   for (int i = 0; i < ATT_MAXQ; ++i) acc[i] = 0.f;
 #pragma unroll 4
   for (int key = half; key < nk; key += 2) {
-    const float* vp = (key < nA) ? (vA + (size_t)key * ldA) : (vB + (size_t)(key - nA) * ldB);
+    const float* kp;
+    const float* vp;
+    keyptr(key, kp, vp);
     const float v = vp[d];
     const float* pr = &S[(size_t)key * ATT_SQ];
 #pragma unroll
@@ -459,9 +456,14 @@ __device__ __forceinline__ void attn_core(const float* __restrict__ q, int ldq, 
 
 enum AttnMode { ATT_ENC = 0, ATT_FULL_SELF = 1, ATT_FULL_CROSS = 2, ATT_STEP_SELF = 3, ATT_STEP_CROSS = 4 };
 
+// Step-mode row layout (one verify step): a running sequence ("slot") owns RPS = 1 + N*D consecutive rows:
+//   row 0                      the token at the row's front (position f) — identical for all N drafts, computed once
+//   row 1 + n*D + (j-1)        token j (1..D) of draft n, at position f + j
+__host__ __device__ inline int step_rps(int N, int D) { return 1 + N * D; }
+
 struct AttnArgs {
   const float* q; int ldq;         // query rows (packed QKV buffer or a plain [M,d] buffer)
-  const float* k; const float* v; int ldkv;   // segment-B / encoder keys (packed QKV buffer) or cross K/V
+  const float* k; const float* v; int ldkv;   // step/encoder keys (packed QKV buffer) or cross K/V
   float* out; int d;               // [M, d]
   float scale;
   int L;                           // ENC: Ls; FULL_*: Lt (queries per row)
@@ -472,85 +474,88 @@ struct AttnArgs {
   // step modes
   const DecState* st; const int* act_idx; const int* front;
   const float* kcache; const float* vcache; long long cache_seq_stride;  // floats per sequence in the cache
-  int gen_ld; int N; int D1;
+  int gen_ld; int N; int D;
   unsigned long long* dbg;         // diagnostic builds only: per-block phase stamps (100 MHz realtime clock)
 };
 
+// Streaming fallback for key counts beyond the LDS images of k_attn2: one wave per (group, head, <=16 queries).
 template <int MODE>
 __global__ __launch_bounds__(64) void k_attn(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int h = blockIdx.y;
+  const int hd = blockIdx.y * ATT_DH;
   const int q0 = blockIdx.z * ATT_MAXQ;
-  const int hd = h * ATT_DH;
-  auto never = [](int) { return true; };
+  const int g = blockIdx.x;
 
-  if constexpr (MODE == ATT_ENC) {
-    const int b = blockIdx.x;
+  if constexpr (MODE == ATT_ENC || MODE == ATT_FULL_SELF || MODE == ATT_FULL_CROSS) {
     const int nq = min(ATT_MAXQ, a.L - q0);
     if (nq <= 0) return;
-    const size_t row0 = (size_t)b * a.L;
-    const int* tk = a.tok + row0;
-    const int pad = a.pad;
-    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
-              a.k + row0 * a.ldkv + hd, a.v + row0 * a.ldkv + hd, a.ldkv, a.L,
-              [=](int key) { return tk[key] != pad; },
-              (const float*)nullptr, (const float*)nullptr, 0, 0, 0, never,
-              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
-  } else if constexpr (MODE == ATT_FULL_SELF) {
-    const int rr = blockIdx.x;
-    const int nq = min(ATT_MAXQ, a.L - q0);
+    const size_t row0 = (size_t)g * a.L;
+    if constexpr (MODE == ATT_FULL_CROSS) {
+      const int mr = a.mem_row ? a.mem_row[g] : g;
+      const size_t mrow0 = (size_t)mr * a.Lk;
+      const uint8_t* kpad = a.key_pad + mrow0;
+      const float* kb = a.k + mrow0 * a.ldkv + hd;
+      const float* vb = a.v + mrow0 * a.ldkv + hd;
+      const int ld = a.ldkv;
+      attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, a.Lk,
+                [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
+                [=](int, int key) { return kpad[key] == 0; },
+                a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+    } else {
+      const int* tk = a.tok + row0;
+      const int pad = a.pad;
+      const float* kb = a.k + row0 * a.ldkv + hd;
+      const float* vb = a.v + row0 * a.ldkv + hd;
+      const int ld = a.ldkv;
+      const bool causal = (MODE == ATT_FULL_SELF);
+      attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, causal ? min(a.L, q0 + nq) : a.L,
+                [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
+                [=](int i, int key) { return tk[key] != pad && (!causal || key <= q0 + i); },
+                a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+    }
+  } else {
+    if (g >= a.st->n_active) return;
+    const int RPS = step_rps(a.N, a.D), D = a.D;
+    const int nq = min(ATT_MAXQ, RPS - q0);
     if (nq <= 0) return;
-    const size_t row0 = (size_t)rr * a.L;
-    const int* tk = a.tok + row0;
-    const int pad = a.pad;
-    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
-              (const float*)nullptr, (const float*)nullptr, 0, 0, never,
-              a.k + row0 * a.ldkv + hd, a.v + row0 * a.ldkv + hd, a.ldkv, min(a.L, q0 + nq), q0,
-              [=](int j) { return tk[j] != pad; },
-              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
-  } else if constexpr (MODE == ATT_FULL_CROSS) {
-    const int rr = blockIdx.x;
-    const int nq = min(ATT_MAXQ, a.L - q0);
-    if (nq <= 0) return;
-    const size_t row0 = (size_t)rr * a.L;
-    const int mr = a.mem_row ? a.mem_row[rr] : rr;
-    const size_t mrow0 = (size_t)mr * a.Lk;
-    const uint8_t* kp = a.key_pad + mrow0;
-    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
-              a.k + mrow0 * a.ldkv + hd, a.v + mrow0 * a.ldkv + hd, a.ldkv, a.Lk,
-              [=](int key) { return kp[key] == 0; },
-              (const float*)nullptr, (const float*)nullptr, 0, 0, 0, never,
-              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
-  } else if constexpr (MODE == ATT_STEP_SELF) {
-    const int rr = blockIdx.x;                   // slot * N + n
-    if (rr >= a.st->r_rows) return;
-    const int nq = min(ATT_MAXQ, a.D1 - q0);
-    if (nq <= 0) return;
-    const int b = a.act_idx[rr / a.N];
-    const int f = a.front[b];
-    const size_t row0 = (size_t)rr * a.D1;
-    const int* tk = a.tok + (size_t)b * a.gen_ld;
-    const int pad = a.pad;
-    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
-              a.kcache + (size_t)b * a.cache_seq_stride + hd, a.vcache + (size_t)b * a.cache_seq_stride + hd, a.d, f,
-              [=](int key) { return tk[key] != pad; },
-              a.k + row0 * a.ldkv + hd, a.v + row0 * a.ldkv + hd, a.ldkv, min(a.D1, q0 + nq), q0,
-              [=](int j) { return j > 0 || tk[f] != pad; },
-              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
-  } else {  // ATT_STEP_CROSS
-    const int rr = blockIdx.x;
-    if (rr >= a.st->r_rows) return;
-    const int nq = min(ATT_MAXQ, a.D1 - q0);
-    if (nq <= 0) return;
-    const int b = a.act_idx[rr / a.N];
-    const size_t row0 = (size_t)rr * a.D1;
-    const size_t mrow0 = (size_t)b * a.Lk;
-    const uint8_t* kv = a.key_pad + mrow0;
-    attn_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq,
-              a.k + mrow0 * a.ldkv + hd, a.v + mrow0 * a.ldkv + hd, a.ldkv, a.Lk,
-              [=](int key) { return kv[key] != 0; },
-              (const float*)nullptr, (const float*)nullptr, 0, 0, 0, never,
-              a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+    const int b = a.act_idx[g];
+    const size_t srow0 = (size_t)g * RPS;              // first step row of this slot
+    if constexpr (MODE == ATT_STEP_SELF) {
+      const int f = a.front[b];
+      const int* tk = a.tok + (size_t)b * a.gen_ld;
+      const int pad = a.pad;
+      const float* kc = a.kcache + (size_t)b * a.cache_seq_stride + hd;
+      const float* vc = a.vcache + (size_t)b * a.cache_seq_stride + hd;
+      const float* kb = a.k + srow0 * a.ldkv + hd;
+      const float* vb = a.v + srow0 * a.ldkv + hd;
+      const int ld = a.ldkv, dd = a.d;
+      const bool front_ok = tk[f] != pad;
+      // keys: cached prefix [0,f), then every step row of the slot (row 0 = position f, draft rows after it)
+      attn_core(a.q + (srow0 + q0) * a.ldq + hd, a.ldq, nq, f + RPS,
+                [=](int key, const float*& kp, const float*& vp) {
+                  if (key < f) { kp = kc + (size_t)key * dd; vp = vc + (size_t)key * dd; }
+                  else { kp = kb + (size_t)(key - f) * ld; vp = vb + (size_t)(key - f) * ld; }
+                },
+                [=](int i, int key) {
+                  if (key < f) return tk[key] != pad;
+                  const int kr = key - f, qr = q0 + i;
+                  if (kr == 0) return front_ok;               // position f is visible to every step row
+                  if (qr == 0) return false;
+                  const int kn = (kr - 1) / D, qn = (qr - 1) / D;
+                  return kn == qn && kr <= qr;                // same draft, not later
+                },
+                a.out + (srow0 + q0) * a.d + hd, a.d, a.scale, lds);
+    } else {
+      const size_t mrow0 = (size_t)b * a.Lk;
+      const uint8_t* kv = a.key_pad + mrow0;
+      const float* kb = a.k + mrow0 * a.ldkv + hd;
+      const float* vb = a.v + mrow0 * a.ldkv + hd;
+      const int ld = a.ldkv;
+      attn_core(a.q + (srow0 + q0) * a.ldq + hd, a.ldq, nq, a.Lk,
+                [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
+                [=](int, int key) { return kv[key] != 0; },
+                a.out + (srow0 + q0) * a.d + hd, a.d, a.scale, lds);
+    }
   }
 }
 
@@ -793,54 +798,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                [=](int qi) { return a2_flag(0, q0 + qi); },
                a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
   } else {
-    // step modes: group = running sequence (slot); a tile holds whole drafts when D+1 <= 32
+    // step modes: group = running sequence (slot); a workgroup takes 64 of the slot's RPS step rows
     const int slot = blockIdx.x;
     if (slot >= a.st->n_active) return;
-    const int D1 = a.D1, N = a.N;
-    int n0, nd, j0, nq;
-    if (D1 <= A2_QT) {
-      const int dpt = A2_QT / D1;
-      n0 = tile * dpt;
-      nd = min(dpt, N - n0);
-      j0 = 0;
-      nq = nd * D1;
-    } else {
-      const int tpd = (D1 + A2_QT - 1) / A2_QT;
-      n0 = tile / tpd;
-      nd = 1;
-      j0 = (tile % tpd) * A2_QT;
-      nq = (n0 < N) ? min(A2_QT, D1 - j0) : 0;
-    }
-    if (nd <= 0 || nq <= 0) return;
+    const int D = a.D, RPS = step_rps(a.N, a.D);
+    const int r0 = tile * A2_QT;                       // first step row of this tile
+    const int nq = min(A2_QT, RPS - r0);
+    if (nq <= 0) return;
     const int b = a.act_idx[slot];
-    const size_t qrow0 = ((size_t)slot * N + n0) * D1 + j0;   // first query row of this tile
-    const size_t drow0 = ((size_t)slot * N + n0) * D1;        // first row of the tile's first draft
+    const size_t srow0 = (size_t)slot * RPS;
     if constexpr (MODE == ATT_STEP_SELF) {
       const int f = a.front[b];
       const int* tk = a.tok + (size_t)b * a.gen_ld;
       const int pad = a.pad;
       const float* kc = a.kcache + (size_t)b * a.cache_seq_stride + hd;
       const float* vc = a.vcache + (size_t)b * a.cache_seq_stride + hd;
-      const float* kb = a.k + drow0 * a.ldkv + hd;
-      const float* vb = a.v + drow0 * a.ldkv + hd;
+      const float* kb = a.k + srow0 * a.ldkv + hd;
+      const float* vb = a.v + srow0 * a.ldkv + hd;
       const int ld = a.ldkv, dd = a.d;
-      const int nB = (D1 <= A2_QT) ? nd * D1 : min(D1, j0 + nq);
-      attn2_core(a.q + qrow0 * a.ldq + hd, a.ldq, nq, f + nB,
+      // keys: cached prefix [0,f) | step row 0 (position f) | the rows of every draft that has a query in this tile
+      const int rlast = r0 + nq - 1;
+      const int n_lo = (r0 == 0) ? 0 : (r0 - 1) / D;
+      const int n_hi = (rlast == 0) ? -1 : (rlast - 1) / D;
+      const int kr0 = 1 + n_lo * D;                    // first draft row staged
+      const int n_draft_keys = (n_hi >= n_lo && D > 0) ? (n_hi - n_lo + 1) * D : 0;
+      attn2_core(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, f + 1 + n_draft_keys,
                  [=](int key, const float*& kp, const float*& vp) {
                    const bool cached = key < f;
-                   const size_t off = cached ? (size_t)key * dd : (size_t)(key - f) * ld;
+                   const int srow = (key == f) ? 0 : kr0 + (key - f - 1);
+                   const size_t off = cached ? (size_t)key * dd : (size_t)srow * ld;
                    kp = (cached ? kc : kb) + off;
                    vp = (cached ? vc : vb) + off;
                  },
                  [=](int key) {
-                   if (key < f) return tk[key] != pad ? A2_ALL : A2_MASKED;
-                   const int kj = key - f;                     // row inside the tile's drafts
-                   const int kd = kj / D1, kp = kj - kd * D1;
-                   if (kp == 0 && tk[f] == pad) return A2_MASKED;   // the front token itself is a PAD key
-                   return a2_flag(kd, kp);
+                   if (key <= f) return tk[key] != pad ? A2_ALL : A2_MASKED;   // prefix and the front token
+                   const int kr = kr0 + (key - f - 1);
+                   const int kn = (kr - 1) / D;
+                   return a2_flag(kn - n_lo, kr - 1 - kn * D);
                  },
-                 [=](int qi) { const int qd = qi / D1; return a2_flag(qd, j0 + qi - qd * D1); },
-                 a.out + qrow0 * a.d + hd, a.d, a.scale, lds,
+                 [=](int qi) {
+                   const int qr = r0 + qi;
+                   if (qr == 0 || D == 0) return a2_flag(0x3fff, 0);           // sees prefix + front token only
+                   const int qn = (qr - 1) / D;
+                   return a2_flag(qn - n_lo, qr - 1 - qn * D);
+                 },
+                 a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, lds,
                  a.dbg ? a.dbg + 8 * (size_t)(blockIdx.x * gridDim.y + blockIdx.y) : nullptr);
     } else {
       const size_t mrow0 = (size_t)b * a.Lk;
@@ -848,10 +850,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       const float* kb = a.k + mrow0 * a.ldkv + hd;
       const float* vb = a.v + mrow0 * a.ldkv + hd;
       const int ld = a.ldkv;
-      attn2_core(a.q + qrow0 * a.ldq + hd, a.ldq, nq, a.Lk,
+      attn2_core(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, a.Lk,
                  [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                  [=](int key) { return kv[key] != 0 ? A2_ALL : A2_MASKED; }, q_any,
-                 a.out + qrow0 * a.d + hd, a.d, a.scale, lds,
+                 a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, lds,
                  a.dbg ? a.dbg + 8 * (size_t)(blockIdx.x * gridDim.y + blockIdx.y) : nullptr);
     }
   }
@@ -875,14 +877,18 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
   int tok, pos;
   if constexpr (STEP) {
     if (row >= a.st->m_rows) return;
-    const int D1 = a.D + 1;
-    const int j = row % D1;
-    const int rn = row / D1;
-    const int n = rn % a.N;
-    const int b = a.act_idx[rn / a.N];
+    const int RPS = step_rps(a.N, a.D);
+    const int rs = row % RPS;                      // row inside the slot (layout: see step_rps)
+    const int b = a.act_idx[row / RPS];
     const int f = a.front[b];
-    tok = (j == 0) ? a.gen[(size_t)b * a.gen_ld + f] : a.drafts[((size_t)b * a.N + n) * a.D + (j - 1)];
-    pos = f + j;
+    if (rs == 0) {
+      tok = a.gen[(size_t)b * a.gen_ld + f];
+      pos = f;
+    } else {
+      const int n = (rs - 1) / a.D, j = (rs - 1) % a.D;          // draft n, token j (0-based) at position f + 1 + j
+      tok = a.drafts[((size_t)b * a.N + n) * a.D + j];
+      pos = f + 1 + j;
+    }
   } else {
     if (row >= a.rows) return;
     tok = a.tok[row];
@@ -988,7 +994,7 @@ __global__ void k_loop_init(LoopArgs a) {
   for (int i = tid; i < a.B; i += gridDim.x * blockDim.x) { a.act_idx[i] = i; a.front[i] = 0; }
   if (tid == 0) {
     DecState s;
-    s.n_active = a.B; s.r_rows = a.B * a.N; s.m_rows = a.B * a.N * (a.D + 1);
+    s.n_active = a.B; s.r_rows = a.B * a.N; s.m_rows = a.B * step_rps(a.N, a.D);
     s.width = 1; s.steps = 0; s.error = 0; s.n_copy = 0;
     s.stop = (1 >= a.max_len) ? 1 : 0;          // `while generated_tokens.size(1) < max_len` (:93)
     if (s.stop) { s.n_active = 0; s.r_rows = 0; s.m_rows = 0; }
@@ -1009,25 +1015,27 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
   DecState* st = a.st;
   const int Bc = st->n_active;
   if (Bc == 0) return;
-  const int D1 = a.D + 1;
+  const int D1 = a.D + 1, RPS = step_rps(a.N, a.D);
   if (threadIdx.x == 0) { s_maxfront = 0; s_anyfin = 0; s_acc = 0; s_prefix = 0; }
   __syncthreads();
   for (int slot = threadIdx.x; slot < Bc; slot += blockDim.x) {
     const int b = a.act_idx[slot];
     const int f = a.front[b];
+    const int* ps = a.pred + (size_t)slot * RPS;       // predictions of the slot's step rows
+    // prediction made at position f + j on draft n: row 0 for j = 0, else row 1 + n*D + (j-1)
     int best = 0, bacc = -1;
     for (int n = 0; n < a.N; ++n) {
       const int* dr = a.drafts + ((size_t)b * a.N + n) * a.D;
-      const int* pr = a.pred + ((size_t)slot * a.N + n) * D1;
+      const int* pr = ps + 1 + n * a.D - 1;            // pr[j] = prediction at position f + j for j >= 1
       int acc = 0;
-      while (acc < a.D && dr[acc] == pr[acc]) ++acc;
+      while (acc < a.D && dr[acc] == (acc == 0 ? ps[0] : pr[acc])) ++acc;
       if (acc > bacc) { bacc = acc; best = n; }
     }
-    const int* pr = a.pred + ((size_t)slot * a.N + best) * D1;
+    const int* pr = ps + 1 + best * a.D - 1;
     int* g = a.gen + (size_t)b * a.gen_ld;
     bool fin = false;
     for (int j = 0; j <= bacc; ++j) {
-      const int t = pr[j];
+      const int t = (j == 0) ? ps[0] : pr[j];
       g[f + 1 + j] = t;
       fin |= (t == a.eos);
     }
@@ -1065,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     st->steps += 1;
     st->accepted += s_acc;
     st->produced += s_acc + Bc;
-    st->verified_positions += (long long)Bc * a.N * D1;
+    st->verified_positions += (long long)Bc * RPS;
     st->kv_prefix_positions += s_prefix;
     st->src_positions += (long long)Bc * a.Ls;
     st->width = width;
@@ -1074,7 +1082,7 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     st->stop = stop;
     st->n_active = stop ? 0 : nn;
     st->r_rows = stop ? 0 : nn * a.N;
-    st->m_rows = stop ? 0 : nn * a.N * D1;
+    st->m_rows = stop ? 0 : nn * RPS;
     a.host->width = width;
     a.host->steps_done = st->steps;
     a.host->stop = stop;
@@ -1130,21 +1138,23 @@ struct KvCopyArgs {
   const DecState* st; const CopyRec* rec;
   const float* qkv; long long qkv_layer_stride;      // [Ld][Mmax][3d]
   float* kcache; float* vcache; long long cache_layer_stride; long long cache_seq_stride;
-  int N, D1, d;
+  int N, D, d;
 };
 
 __global__ __launch_bounds__(256) void k_kvcopy(KvCopyArgs a) {
   const int slot = blockIdx.x, l = blockIdx.y;
   if (slot >= a.st->n_copy) return;
   const CopyRec r = a.rec[slot];
-  const float* src = a.qkv + (size_t)l * a.qkv_layer_stride + ((size_t)(slot * a.N + r.best) * a.D1) * 3 * a.d;
+  const int RPS = step_rps(a.N, a.D);
+  const float* src = a.qkv + (size_t)l * a.qkv_layer_stride + ((size_t)slot * RPS) * 3 * a.d;   // the slot's step rows
   float* kc = a.kcache + (size_t)l * a.cache_layer_stride + (size_t)r.b * a.cache_seq_stride + (size_t)r.front_old * a.d;
   float* vc = a.vcache + (size_t)l * a.cache_layer_stride + (size_t)r.b * a.cache_seq_stride + (size_t)r.front_old * a.d;
   const int per_row = a.d / 4;                    // float4 per K (or V) row
   const int total = (r.nacc + 1) * per_row;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int j = e / per_row, c = (e % per_row) * 4;
-    const float* p = src + (size_t)j * 3 * a.d;
+    const int srow = (j == 0) ? 0 : 1 + r.best * a.D + (j - 1);   // position front_old + j of the chosen draft
+    const float* p = src + (size_t)srow * 3 * a.d;
     *reinterpret_cast<float4*>(kc + (size_t)j * a.d + c) = *reinterpret_cast<const float4*>(p + a.d + c);
     *reinterpret_cast<float4*>(vc + (size_t)j * a.d + c) = *reinterpret_cast<const float4*>(p + 2 * a.d + c);
   }
