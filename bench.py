@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--max-len", type=int, default=200)
     ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "2500")))
     ap.add_argument("--cpu-batches", type=int, default=1, help="batches of the workload timed on the host cores")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("TTX_INFLIGHT", "1")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("TTX_INFLIGHT", "8")),
                     help="batches decoded concurrently per GPU (1 = the reference's one-batch-at-a-time loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -115,13 +115,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and os.environ.get("TTX_SHARE_GPU") != "1":
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({n_dev} visible)")
+    local_rank = local_rank % n_dev          # TTX_SHARE_GPU=1: rehearsal of the N>1 path on a 1-GPU box
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl")   # RCCL over xGMI
+        dist.init_process_group(os.environ.get("TTX_DIST_BACKEND", "nccl"))   # "nccl" = RCCL over xGMI
 
     import translation_transformer_amd as tta
     from tools.synth import SynthReactions, batches, PAD, BOS, EOS, C_TOK, V
@@ -166,7 +170,7 @@ def main():
     elapsed = time.perf_counter() - t0
     log("timed region done", elapsed, "s", gen.model_calls_num, "calls")
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -200,6 +204,16 @@ def main():
         line["hbm_algorithmic"] = {"bytes_per_reaction": work["bytes"] / (len(timed) * a.batch_size),
                                    "achieved_GBs": work["bytes"] / elapsed / 1e9,
                                    "frac_of_peak": work["bytes"] / elapsed / 1e9 / PEAK_HBM_GBS}
+        if a.inflight > 1:
+            # the same K batches strictly one at a time (the reference's predict loop), for comparison
+            g1 = make_gen(model)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            seq = [g1.generate(b) for b in timed]
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            line["one_batch_at_a_time"] = {"value": len(timed) * a.batch_size / dt1, "unit": "reactions/s",
+                                           "identical_to_in_flight_outputs": all(torch.equal(x, y) for x, y in zip(seq, outs))}
         if not a.no_profile:
             # dominant kernel = k_gemm_tn (fp32 MFMA GEMM): HIP events on the launch stream around every launch,
             # same batches, same process, right after the timed region
@@ -208,20 +222,26 @@ def main():
             os.environ.pop("TTX_PROFILE_GEMM")
             pg = make_gen(pm)
             import ctypes as C
-            gemm_ms, launches = 0.0, 0
+            gemm_ms, launches, empty_ms = 0.0, 0, 0.0
             for b in timed:
                 pg.generate(b)
-                ms, n = C.c_double(), C.c_int64()
-                pm._lib.ttx_last_kernel_profile(pm.session, C.byref(ms), C.byref(n))
+                ms, n, e = C.c_double(), C.c_int64(), C.c_double()
+                pm._lib.ttx_last_kernel_profile(pm.session, C.byref(ms), C.byref(n), C.byref(e))
                 gemm_ms += ms.value
                 launches += n.value
+                empty_ms = e.value
+            raw_ms = gemm_ms
+            gemm_ms = max(1e-9, gemm_ms - launches * empty_ms)     # remove the event-pair overhead of every launch
             pstats = dict(pg.stats_total)
             pstats["model_calls"] = pg.model_calls_num
             pw = flops_and_bytes(cfg, pstats, pstats["src_tokens_padded"], len(timed))
             ach = pw["gemm_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-            line["roofline"] = {"kernel": "k_gemm_tn (fp32 v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach,
+            line["roofline"] = {"kernel": "k_gemm2 / k_gemm_tn (fp32 v_mfma_f32_32x32x2_f32 GEMM, every launch of the run)",
+                                "bound": "mfma", "achieved": ach,
                                 "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
                                 "traffic": None, "launches": launches, "avg_launch_us": 1e3 * gemm_ms / max(1, launches),
+                                "avg_launch_us_with_event_pair": 1e3 * raw_ms / max(1, launches),
+                                "event_pair_overhead_us": 1e3 * empty_ms,
                                 "flops_per_launch": pw["gemm_flops"] / max(1, launches),
                                 "gemm_share_of_decode_time": gemm_ms / max(1e-9, pstats["encode_ms"] + pstats["decode_ms"])}
             pm.close()

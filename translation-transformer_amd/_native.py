@@ -73,7 +73,7 @@ SYMBOLS = {
     "ttx_greedy_speculative_generate_many": (C.c_int, [C.POINTER(_VP), _I, _I, C.POINTER(_VP), C.POINTER(C.c_int),
                                                       C.POINTER(C.c_int), C.POINTER(GenParams), C.POINTER(_VP),
                                                       C.POINTER(GenStats), _VP]),
-    "ttx_last_kernel_profile": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ttx_last_kernel_profile": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 
 _lib = None

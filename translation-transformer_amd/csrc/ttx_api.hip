@@ -3,6 +3,7 @@
 #include "ttx.h"
 #include "ttx_kernels.hip.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -285,6 +286,10 @@ struct ttx_session {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double prof_ms = 0;
+  double prof_empty_pair_ms = -1;
+  bool host_timing = false;
+  double host_launch_us = 0;
+  long long host_launches = 0;
   long long prof_launches = 0;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
   ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
@@ -331,12 +336,16 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   s->gemm_v1 = getenv("TTX_GEMM_V1") != nullptr;
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
+  s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
   *out = s;
   return TTX_OK;
 }
 
 extern "C" void ttx_session_destroy(ttx_session* s) {
   if (!s) return;
+  if (s->host_timing && s->host_launches)
+    fprintf(stderr, "[ttx host timing] hipGraphLaunch: %lld launches, %.1f us each\n", s->host_launches,
+            s->host_launch_us / (double)s->host_launches);
   (void)hipDeviceSynchronize();
   for (Buf* b : s->all)
     if (b->p) (void)hipFree(b->p);
@@ -441,8 +450,8 @@ static int launch_attn(ttx_session* s, hipStream_t st, const AttnArgs& a, int gr
   const int D = D1 - 1;
   const int draft_keys = (D > 0) ? (std::min(N, (A2_QT + D - 2) / D + 1)) * D : 0;
   const int keys2 = (MODE == ATT_STEP_SELF) ? max_keys + 1 + draft_keys : max_keys;
-  const size_t lds2 = attn2_lds_bytes(keys2);
-  if (lds2 <= kAttn2LdsLimit && !s->attn_v1) {
+  const size_t lds2 = attn2_lds_bytes(keys2, a2_qcap(q_per_group));
+  if (lds2 <= kAttn2LdsLimit && attn2_fits(keys2) && !s->attn_v1) {
     const int tiles = cdiv(q_per_group, A2_QT);
     static bool attr_set[8] = {false, false, false, false, false, false, false, false};
     if (lds2 > 64 * 1024 && !attr_set[MODE]) {
@@ -899,7 +908,14 @@ static int gen_launch_step(GenJob& j, int width_bound) {
     if (s->graphs.size() > 512) s->drop_graphs();
     it = s->graphs.emplace(key, exec).first;
   }
-  HIP_TRY(hipGraphLaunch(it->second, j.st));
+  if (s->host_timing) {
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipGraphLaunch(it->second, j.st));
+    s->host_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    s->host_launches += 1;
+  } else {
+    HIP_TRY(hipGraphLaunch(it->second, j.st));
+  }
   ++j.launched;
   return TTX_OK;
 }
@@ -943,6 +959,20 @@ static int gen_finish_collect(GenJob& j) {
     for (size_t i = 0; i < s->ev_used; ++i) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) s->prof_ms += ms;
+    }
+    // what an empty event pair costs on this stream (no kernel between the two records): reported beside the raw sum
+    if (s->prof_empty_pair_ms < 0 && s->ev_pool.size() >= 64) {
+      for (int i = 0; i < 64; ++i) {
+        (void)hipEventRecord(s->ev_pool[i].first, j.st);
+        (void)hipEventRecord(s->ev_pool[i].second, j.st);
+      }
+      (void)hipStreamSynchronize(j.st);
+      double acc = 0;
+      for (int i = 0; i < 64; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) acc += ms;
+      }
+      s->prof_empty_pair_ms = acc / 64.0;
     }
   }
   if (s->attn_debug) {
@@ -1085,9 +1115,10 @@ extern "C" int ttx_greedy_speculative_generate_many(ttx_session** sessions, int 
   return rc_final;
 }
 
-extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches) {
+extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms) {
   if (!s) return fail(TTX_ERR_INVALID, "null session");
   if (gemm_ms) *gemm_ms = s->prof_ms;
   if (gemm_launches) *gemm_launches = s->prof_launches;
+  if (empty_pair_ms) *empty_pair_ms = s->prof_empty_pair_ms < 0 ? 0.0 : s->prof_empty_pair_ms;
   return TTX_OK;
 }

@@ -149,6 +149,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_tn(GemmArgs a) {
 // therefore keeps a ring of four 64-deep K tiles in flight in registers (all of K = 256 is requested
 // from L2/Infinity Cache before the first MFMA), LDS is double-buffered so one barrier per tile
 // suffices, and the 64x64 output tile is four 32x32 fp32-MFMA accumulators, one per wave.
+#ifndef TTX_G2_BUFS
+#define TTX_G2_BUFS 2
+#endif
 struct G2Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
 struct G2Ptrs { const float* x0; const float* x1; const float* x2; const float* x3;
                 const float* w0; const float* w1; const float* w2; const float* w3; };
@@ -199,8 +202,8 @@ __device__ __forceinline__ void g2_mma(f32x16& acc, const float* ap, const float
 template <int NT>
 __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
   constexpr int BM = 64, BN = 64, BK = 64, LDT = BK + 4, RING = 4;
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
+  __shared__ __attribute__((aligned(16))) float As[TTX_G2_BUFS][BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[TTX_G2_BUFS][BN * LDT];
 
   const int M = a.m_ptr ? *a.m_ptr : a.M;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -239,14 +242,20 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
     g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
     __syncthreads();
     g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
+      if (TTX_G2_BUFS == 1) __syncthreads();
   } else if constexpr (NT == 2) {
     const G2Frag f0 = g2_load(p, 0);
     const G2Frag f1 = g2_load(p, BK);
     g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
-    g2_store<LDT>(f1, As[1], Bs[1], lr, lc);
+    if (TTX_G2_BUFS == 2) g2_store<LDT>(f1, As[TTX_G2_BUFS - 1], Bs[TTX_G2_BUFS - 1], lr, lc);
     __syncthreads();
     g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
-    g2_mma<BK, LDT>(acc, As[1] + aoff, Bs[1] + boff);
+    if (TTX_G2_BUFS == 1) {
+      __syncthreads();
+      g2_store<LDT>(f1, As[0], Bs[0], lr, lc);
+      __syncthreads();
+    }
+    g2_mma<BK, LDT>(acc, As[TTX_G2_BUFS - 1] + aoff, Bs[TTX_G2_BUFS - 1] + boff);
   } else {
     // ring of four register tiles, two LDS buffers; slot indices are compile-time (no register moves:
     // moving a pending load's destination would force a wait on it)
@@ -260,18 +269,22 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
       if constexpr (NT == 0) f0 = g2_load(p, min(base + RING, last) * BK);      // clamped: branch-free refill
       __syncthreads();
       g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
-      g2_store<LDT>(f1, As[1], Bs[1], lr, lc);
+      if (TTX_G2_BUFS == 1) __syncthreads();
+      g2_store<LDT>(f1, As[TTX_G2_BUFS - 1], Bs[TTX_G2_BUFS - 1], lr, lc);
       if constexpr (NT == 0) f1 = g2_load(p, min(base + RING + 1, last) * BK);
       __syncthreads();
-      g2_mma<BK, LDT>(acc, As[1] + aoff, Bs[1] + boff);
+      g2_mma<BK, LDT>(acc, As[TTX_G2_BUFS - 1] + aoff, Bs[TTX_G2_BUFS - 1] + boff);
+      if (TTX_G2_BUFS == 1) __syncthreads();
       g2_store<LDT>(f2, As[0], Bs[0], lr, lc);
       if constexpr (NT == 0) f2 = g2_load(p, min(base + RING + 2, last) * BK);
       __syncthreads();
       g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
-      g2_store<LDT>(f3, As[1], Bs[1], lr, lc);
+      if (TTX_G2_BUFS == 1) __syncthreads();
+      g2_store<LDT>(f3, As[TTX_G2_BUFS - 1], Bs[TTX_G2_BUFS - 1], lr, lc);
       if constexpr (NT == 0) f3 = g2_load(p, min(base + RING + 3, last) * BK);
       __syncthreads();
-      g2_mma<BK, LDT>(acc, As[1] + aoff, Bs[1] + boff);
+      g2_mma<BK, LDT>(acc, As[TTX_G2_BUFS - 1] + aoff, Bs[TTX_G2_BUFS - 1] + boff);
+      if (TTX_G2_BUFS == 1) __syncthreads();
     }
   }
 
@@ -571,12 +584,19 @@ constexpr int A2_QT = 64;                  // queries per workgroup (two MFMA ro
 constexpr int A2_LDQ = ATT_DH + 4;         // LDS row stride of Q and K rows (conflict-free ds_read_b128)
 
 __host__ __device__ inline int a2_nkp(int nk) { return (nk + 31) & ~31; }
-__host__ __device__ inline size_t attn2_lds_bytes(int max_keys) {
+constexpr int A2_OP = 4 * A2_MT * 33;      // floats of the four waves' partial output tiles (aliased onto the score image)
+constexpr int A2_VSTEPS = 12;              // V rows held in registers: 8 keys per step per wave -> up to 384 keys
+__host__ __device__ inline int a2_qcap(int q_per_group) { return q_per_group <= A2_MT ? A2_MT : A2_QT; }
+__host__ __device__ inline size_t a2_score_floats(int nkp) {
+  const size_t sf = (size_t)A2_MT * (nkp + 4);
+  return sf > (size_t)A2_OP ? sf : (size_t)A2_OP;
+}
+__host__ __device__ inline size_t attn2_lds_bytes(int max_keys, int qcap) {
   const size_t nkp = a2_nkp(max_keys);
-  return sizeof(float) * ((size_t)A2_QT * A2_LDQ + nkp * A2_LDQ + nkp * ATT_DH + (size_t)A2_MT * (nkp + 4) + A2_MT +
-                          (size_t)4 * A2_MT * 33) +
+  return sizeof(float) * ((size_t)qcap * A2_LDQ + nkp * A2_LDQ + a2_score_floats((int)nkp) + A2_MT) +
          sizeof(int) * (nkp + A2_QT);
 }
+__host__ __device__ inline bool attn2_fits(int max_keys) { return a2_nkp(max_keys) <= 32 * A2_VSTEPS; }
 
 // Visibility is decided from one int per key and one per query, computed once while staging:
 //   key flag A2_MASKED   masked (PAD key / padding row)
@@ -594,7 +614,7 @@ __device__ __forceinline__ bool a2_visible(int qf, int kf) {
 // keyptr(key, kp, vp): branch-free K/V row pointers of key (0 <= key < nk); keyflag(key), qflag(qi): see above.
 template <class KeyPtr, class KeyFlag, class QFlag>
 __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq, int nq, int nk, KeyPtr keyptr, KeyFlag keyflag,
-                                           QFlag qflag, float* __restrict__ out, int ldo, float scale, float* lds,
+                                           QFlag qflag, float* __restrict__ out, int ldo, float scale, float* lds, int qcap,
                                            unsigned long long* dbg = nullptr) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
@@ -602,13 +622,12 @@ __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq,
 #define TTX_STAMP(i) do { if (dbg && t == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
   TTX_STAMP(0);
   const int lds_s = nkp + 4;
-  float* Qs = lds;                                   // [64][36]
-  float* Ks = Qs + A2_QT * A2_LDQ;                   // [nkp][36]
-  float* Vs = Ks + (size_t)nkp * A2_LDQ;             // [nkp][32]
-  float* S = Vs + (size_t)nkp * ATT_DH;              // [32][nkp+4]   scores of the current row tile
-  float* inv = S + (size_t)A2_MT * lds_s;            // [32]
-  float* Op = inv + A2_MT;                           // [4 waves][32][33] partial outputs
-  int* kfl = reinterpret_cast<int*>(Op + 4 * A2_MT * 33);   // [nkp]
+  float* Qs = lds;                                   // [qcap][36]
+  float* Ks = Qs + qcap * A2_LDQ;                    // [nkp][36]
+  float* S = Ks + (size_t)nkp * A2_LDQ;              // [32][nkp+4]   scores of the current row tile
+  float* Op = S;                                     // [4 waves][32][33] partial outputs reuse the score image
+  float* inv = S + a2_score_floats(nkp);             // [32]
+  int* kfl = reinterpret_cast<int*>(inv + A2_MT);    // [nkp]
   int* qfl = kfl + nkp;                              // [64]
 
   // ---- stage Q, K, V: a row is 32 floats = 8 lanes x float4.  Loads are unconditional (indices are clamped;
@@ -616,37 +635,50 @@ __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq,
   const int lr = t >> 3, lc = (t & 7) * 4;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x4 qv0 = *reinterpret_cast<const f32x4*>(q + (size_t)min(lr, nq - 1) * ldq + lc);
-  f32x4 qv1 = *reinterpret_cast<const f32x4*>(q + (size_t)min(lr + 32, nq - 1) * ldq + lc);
+  f32x4 qv1 = qv0;
+  if (qcap > A2_MT) qv1 = *reinterpret_cast<const f32x4*>(q + (size_t)min(lr + 32, nq - 1) * ldq + lc);
   constexpr int A2_U = 8;                            // passes of 32 keys in flight
+  // V never touches LDS: in O = P·V lane (dh, h) needs V[key][dh] for its wave's keys only, so each wave keeps its
+  // nkp/4 value rows in registers (requested here, consumed after the softmax)
+  const int kq = nkp / 4;
+  float vr[A2_VSTEPS][4];
   for (int k0 = 0; k0 < nkp; k0 += 32 * A2_U) {
-    f32x4 kv[A2_U], vv[A2_U];
+    f32x4 kv[A2_U];
 #pragma unroll
     for (int u = 0; u < A2_U; ++u) {
       const float* kp;
       const float* vp;
       keyptr(min(k0 + u * 32 + lr, nk - 1), kp, vp);
       kv[u] = *reinterpret_cast<const f32x4*>(kp + lc);
-      vv[u] = *reinterpret_cast<const f32x4*>(vp + lc);
     }
-    if (k0 == 0) {   // the visibility flags' token loads ride behind the K/V requests
+    if (k0 == 0) {
+#pragma unroll
+      for (int si = 0; si < A2_VSTEPS; ++si) {
+        if (si * 8 < kq) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float* kp;
+            const float* vp;
+            keyptr(min(wave * kq + si * 8 + 4 * h + jj, nk - 1), kp, vp);
+            vr[si][jj] = vp[r];
+          }
+        }
+      }
+      // the visibility flags' token loads ride behind the K/V requests
       for (int key = t; key < nkp; key += 256) kfl[key] = (key < nk) ? keyflag(key) : A2_MASKED;
       if (t < A2_QT) qfl[t] = qflag(t);
     }
-    // every request is in flight before the first value is consumed: the empty asm reads all sixteen
-    // registers, so the scheduler cannot sink a load down to its LDS write
-    asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(kv[4]), "+v"(kv[5]), "+v"(kv[6]), "+v"(kv[7]),
-                      "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]));
+    // every K request is in flight before the first value is consumed: the empty asm reads all eight registers,
+    // so the scheduler cannot sink a load down to its LDS write
+    asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(kv[4]), "+v"(kv[5]), "+v"(kv[6]), "+v"(kv[7]));
 #pragma unroll
     for (int u = 0; u < A2_U; ++u) {
       const int key = k0 + u * 32 + lr;
-      if (k0 + u * 32 < nkp) {
-        *reinterpret_cast<f32x4*>(&Ks[(size_t)key * A2_LDQ + lc]) = kv[u];
-        *reinterpret_cast<f32x4*>(&Vs[(size_t)key * ATT_DH + lc]) = vv[u];
-      }
+      if (k0 + u * 32 < nkp) *reinterpret_cast<f32x4*>(&Ks[(size_t)key * A2_LDQ + lc]) = kv[u];
     }
   }
   *reinterpret_cast<f32x4*>(&Qs[lr * A2_LDQ + lc]) = qv0;
-  *reinterpret_cast<f32x4*>(&Qs[(lr + 32) * A2_LDQ + lc]) = qv1;
+  if (qcap > A2_MT) *reinterpret_cast<f32x4*>(&Qs[(lr + 32) * A2_LDQ + lc]) = qv1;
   __syncthreads();
   TTX_STAMP(1);
 
@@ -710,21 +742,23 @@ __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq,
     __syncthreads();
     if (mt == 0) TTX_STAMP(3);
 
-    // ---- O = P V: wave w takes keys [w*nkp/4, (w+1)*nkp/4), partial sums meet in LDS
+    // ---- O = P V: wave w takes keys [w*nkp/4, (w+1)*nkp/4) with its V rows from registers; partial sums meet in LDS
     {
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-      const int kq = nkp / 4;
-      const float* prow = S + (size_t)r * lds_s + 4 * h;
-      for (int kb = wave * kq; kb < (wave + 1) * kq; kb += 8) {
-        const float4 pv = *reinterpret_cast<const float4*>(prow + kb);
-        const float* vb = Vs + (size_t)(kb + 4 * h) * ATT_DH + r;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.x, vb[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.y, vb[ATT_DH], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.z, vb[2 * ATT_DH], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.w, vb[3 * ATT_DH], acc, 0, 0, 0);
+      const float* prow = S + (size_t)r * lds_s + 4 * h + wave * kq;
+#pragma unroll
+      for (int si = 0; si < A2_VSTEPS; ++si) {
+        if (si * 8 < kq) {
+          const float4 pv = *reinterpret_cast<const float4*>(prow + si * 8);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.x, vr[si][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.y, vr[si][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.z, vr[si][2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.w, vr[si][3], acc, 0, 0, 0);
+        }
       }
+      __syncthreads();                                // every wave has read its P columns: the image becomes Op
       float* part = Op + (size_t)wave * (A2_MT * 33);
 #pragma unroll
       for (int v = 0; v < 16; ++v) part[((v & 3) + 8 * (v >> 2) + 4 * h) * 33 + r] = acc[v];
@@ -768,7 +802,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       attn2_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, a.L,
                  [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                  [=](int key) { return tk[key] != pad ? A2_ALL : A2_MASKED; }, q_any,
-                 a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+                 a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds, a2_qcap(a.L));
     } else {
       const int mr = a.mem_row ? a.mem_row[g] : g;
       const size_t mrow0 = (size_t)mr * a.Lk;
@@ -779,7 +813,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       attn2_core(a.q + (row0 + q0) * a.ldq + hd, a.ldq, nq, a.Lk,
                  [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                  [=](int key) { return kpad[key] == 0 ? A2_ALL : A2_MASKED; }, q_any,
-                 a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+                 a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds, a2_qcap(a.L));
     }
   } else if constexpr (MODE == ATT_FULL_SELF) {
     const int g = blockIdx.x;
@@ -796,7 +830,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                [=](int key) { return tk[key] != pad ? a2_flag(0, key) : A2_MASKED; },
                [=](int qi) { return a2_flag(0, q0 + qi); },
-               a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds);
+               a.out + (row0 + q0) * a.d + hd, a.d, a.scale, lds, a2_qcap(a.L));
   } else {
     // step modes: group = running sequence (slot); a workgroup takes 64 of the slot's RPS step rows
     const int slot = blockIdx.x;
@@ -842,7 +876,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                    const int qn = (qr - 1) / D;
                    return a2_flag(qn - n_lo, qr - 1 - qn * D);
                  },
-                 a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, lds,
+                 a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, lds, a2_qcap(RPS),
                  a.dbg ? a.dbg + 8 * (size_t)(blockIdx.x * gridDim.y + blockIdx.y) : nullptr);
     } else {
       const size_t mrow0 = (size_t)b * a.Lk;
@@ -853,7 +887,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       attn2_core(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, a.Lk,
                  [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                  [=](int key) { return kv[key] != 0 ? A2_ALL : A2_MASKED; }, q_any,
-                 a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, lds,
+                 a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, lds, a2_qcap(RPS),
                  a.dbg ? a.dbg + 8 * (size_t)(blockIdx.x * gridDim.y + blockIdx.y) : nullptr);
     }
   }

@@ -18,12 +18,18 @@ def shard_bounds(n_items: int, rank: int, world: int) -> tuple[int, int]:
     return lo, min(n_items, lo + per)
 
 
+def _wire_device(device, dist):
+    """Collectives run on the GPU under RCCL ("nccl") and on host memory under gloo (CPU tests, rehearsals)."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else torch.device(device)
+
+
 def broadcast_state_dict(state: dict | None, device: torch.device | str, dist=None, src: int = 0) -> dict:
     """C1.  Rank `src` passes its state dict (name -> tensor); every rank returns the same dict (CPU fp32).
     One broadcast of names/shapes (tiny, object) + ONE broadcast of the flat fp32 blob (46 MB for the MIT model)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return {k: torch.as_tensor(v).float().cpu() for k, v in state.items()}
     rank = dist.get_rank()
+    device = _wire_device(device, dist)
     meta = [None]
     if rank == src:
         names = list(state.keys())
@@ -49,6 +55,8 @@ def gather_predictions(local: torch.Tensor, n_items: int, dist=None, dst: int = 
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
+    home = local.device
+    local = local.to(_wire_device(home, dist))
     per = math.ceil(n_items / world)
     dt = torch.int32            # token ids; every rank must agree on the wire type
     width = torch.tensor([local.shape[2] if local.numel() else 0], dtype=torch.int64, device=local.device)
@@ -64,7 +72,7 @@ def gather_predictions(local: torch.Tensor, n_items: int, dist=None, dst: int = 
     for r, p in enumerate(parts):
         lo, hi = shard_bounds(n_items, r, world)
         out.append(p[:hi - lo])
-    return torch.cat(out).to(torch.int64)
+    return torch.cat(out).to(torch.int64).to(home)
 
 
 def sum_counters(values: dict, device, dist=None) -> dict:
@@ -72,6 +80,6 @@ def sum_counters(values: dict, device, dist=None) -> dict:
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return dict(values)
     keys = sorted(values)
-    t = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=device)
+    t = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=_wire_device(device, dist))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return {k: t[i].item() for i, k in enumerate(keys)}
