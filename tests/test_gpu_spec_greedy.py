@@ -59,3 +59,78 @@ def test_many_batches_in_flight_equal_one_at_a_time(tta, tiny):
         for a, b in zip(out, ref):
             assert torch.equal(a, b)
         assert g2.model_calls_num == g1.model_calls_num
+
+
+def _random_sources(n, lo, hi, V, seed):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        body = rng.integers(4, V, size=L - 2)
+        rows.append(np.concatenate([[BOS], body, [EOS]]))
+    W = max(len(r) for r in rows)
+    out = np.full((n, W), PAD, dtype=np.int64)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = r
+    return torch.from_numpy(out)
+
+
+def test_large_ragged_batch_matches_oracle(tta, tiny):
+    """300 ragged random sources in ONE batch (more rows than one accept-kernel pass of 256 threads; rows that
+    never reach EOS stay PAD; short max_len so the width rule ends the loop) against the oracle."""
+    from oracle.model import OracleTransformer, config_from_state
+    from oracle.decoding import GreedySpeculativeOracle
+    st, cfg = tiny_state()
+    oracle = OracleTransformer(config_from_state(st, cfg["num_heads"]), st)
+    _, _, c, V = fixture_tokens()
+    src = _random_sources(300, 6, 60, V, seed=3)
+    outcomes = []
+    for max_len, N, D in ((40, 3, 10), (64, 2, 4), (120, 3, 10), (150, 5, 6)):
+        exp = GreedySpeculativeOracle(oracle, max_len, D, N, PAD, BOS, EOS, c)
+        g = tta.TranslationInferenceGreedySpeculative(tiny, max_len, D, N, PAD, BOS, EOS, c)
+        try:
+            want = exp.generate(src)
+        except RuntimeError:
+            # the reference raises here (a row reaches EOS while the tensor is already wider than max_len,
+            # speculative_decoding.py:158): the HIP path must report the same condition, not invent an output
+            with pytest.raises(tta.ReferenceError_):
+                g.generate(src.cuda())
+            outcomes.append("raises")
+            continue
+        got = g.generate(src.cuda()).cpu()
+        assert torch.equal(got, want)
+        assert g.model_calls_num == exp.model_calls_num
+        outcomes.append("equal")
+    print("large ragged batch:", outcomes)
+    assert "equal" in outcomes
+
+
+def test_streaming_attention_fallback_matches(tta):
+    """The long-sequence attention kernel (k_attn, used when the LDS images of k_attn2 do not fit) on the same
+    inputs as the fast path."""
+    import os
+    gold = load_npz("gen_spec_greedy.npz")
+    src, _, c, _ = fixture_tokens()
+    st, cfg = tiny_state()
+    os.environ["TTX_ATTN_V1"] = "1"
+    try:
+        slow = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    finally:
+        os.environ.pop("TTX_ATTN_V1")
+    g = tta.TranslationInferenceGreedySpeculative(slow, 150, 10, 3, PAD, BOS, EOS, c)
+    np.testing.assert_array_equal(g.generate(src.cuda()).cpu().numpy(), gold["b10_n3_d10_tokens"])
+    io = load_npz("tiny_model_io.npz")
+    mem = slow.encode_src(torch.from_numpy(io["src"]).cuda()).cpu()
+    mask = torch.from_numpy(io["src"]) == 0
+    assert (mem - torch.from_numpy(io["memory"]))[~mask].abs().max() < 1e-4
+    slow.close()
+
+
+def test_reference_error_cases(tta, tiny):
+    src, _, c, _ = fixture_tokens()
+    with pytest.raises(tta.ReferenceError_):      # drafting.py:39 "The number of drafts must be greater than 0"
+        tta.TranslationInferenceGreedySpeculative(tiny, 150, 10, 0, PAD, BOS, EOS, c).generate(src.cuda())
+    with pytest.raises(tta.ReferenceError_):      # drafting.py:41 pad token == replace token
+        tta.TranslationInferenceGreedySpeculative(tiny, 150, 10, 3, PAD, BOS, EOS, PAD).generate(src.cuda())
+    out = tta.TranslationInferenceGreedySpeculative(tiny, 1, 1, 1, PAD, BOS, EOS, c).generate(src.cuda())
+    assert out.shape == (10, 1, 1) and int((out != PAD).sum()) == 0     # `while size(1) < max_len` never entered

@@ -267,7 +267,7 @@ struct ttx_session {
   // full decoder
   Buf tok_tgt, mem_pad_tmp;
   // loop
-  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf, dbg_self, dbg_cross;
+  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf, dbg_self, dbg_cross, haspad;
   bool attn_debug = false;
   HostInfo* host_info = nullptr;   // pinned + device-mapped, written by the accept kernels
   hipStream_t own_stream = nullptr; // used by the many-batches driver
@@ -294,7 +294,7 @@ struct ttx_session {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
   ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
-                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross}) all.push_back(b); }
+                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad}) all.push_back(b); }
 };
 
 static thread_local uint64_t* g_alloc_gen = nullptr;   // alloc_generation of the session being sized
@@ -812,6 +812,7 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   TTX_TRY(ensure(s->gen, (size_t)B * g.k.gen_ld * 4, st));
   TTX_TRY(ensure(s->front, (size_t)B * 4, st));
   TTX_TRY(ensure(s->act_idx, (size_t)B * 4, st));
+  TTX_TRY(ensure(s->haspad, (size_t)B * 4, st));
   TTX_TRY(ensure(s->rec, (size_t)B * sizeof(CopyRec), st));
   TTX_TRY(ensure(s->pred, Mmax * 4, st));
   TTX_TRY(ensure(s->state, sizeof(DecState), st));
@@ -847,7 +848,7 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
 
   g.la.st = s->state.as<DecState>(); g.la.act_idx = s->act_idx.as<int>(); g.la.front = s->front.as<int>();
   g.la.gen = s->gen.as<int>(); g.la.gen_ld = g.k.gen_ld; g.la.drafts = s->drafts.as<int>(); g.la.pred = s->pred.as<int>();
-  g.la.rec = s->rec.as<CopyRec>(); g.la.out = s->outbuf.as<int64_t>();
+  g.la.rec = s->rec.as<CopyRec>(); g.la.out = s->outbuf.as<int64_t>(); g.la.haspad = s->haspad.as<int>();
   HostInfo* dev_info = nullptr;
   HIP_TRY(hipHostGetDevicePointer((void**)&dev_info, (void*)s->host_info, 0));
   g.la.host = dev_info;
@@ -997,6 +998,9 @@ static int gen_finish_collect(GenJob& j) {
     }
   }
   j.phase = 0;
+  if (hs.error == 2)
+    return fail(TTX_ERR_REFERENCE, "the model emitted PAD inside a sequence and a whole column became PAD: the reference's draft "
+                                   "scatter raises 'index out of range' here (speculative_decoding.py:97,111-115)");
   if (hs.error) return fail(TTX_ERR_REFERENCE, "a row finished at a width beyond max_len: shape mismatch in the reference (speculative_decoding.py:158)");
   return TTX_OK;
 }

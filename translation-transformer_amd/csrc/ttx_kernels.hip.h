@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(64) void k_make_drafts(const int* src, int src_ld, 
 struct LoopArgs {
   DecState* st; int* act_idx; int* front; int* gen; int gen_ld;
   const int* drafts; const int* pred;
-  CopyRec* rec; int64_t* out; HostInfo* host;
+  CopyRec* rec; int64_t* out; HostInfo* host; int* haspad;
   int B, N, D, Ls, max_len, pad, bos, eos;
 };
 
@@ -1025,7 +1025,7 @@ __global__ void k_loop_init(LoopArgs a) {
   const int total = a.B * a.gen_ld;
   for (int i = tid; i < total; i += gridDim.x * blockDim.x) a.gen[i] = (i % a.gen_ld == 0) ? a.bos : a.pad;
   for (int i = tid; i < a.B * a.max_len; i += gridDim.x * blockDim.x) a.out[i] = a.pad;
-  for (int i = tid; i < a.B; i += gridDim.x * blockDim.x) { a.act_idx[i] = i; a.front[i] = 0; }
+  for (int i = tid; i < a.B; i += gridDim.x * blockDim.x) { a.act_idx[i] = i; a.front[i] = 0; a.haspad[i] = 0; }
   if (tid == 0) {
     DecState s;
     s.n_active = a.B; s.r_rows = a.B * a.N; s.m_rows = a.B * step_rps(a.N, a.D);
@@ -1072,6 +1072,7 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
       const int t = (j == 0) ? ps[0] : pr[j];
       g[f + 1 + j] = t;
       fin |= (t == a.eos);
+      if (t == a.pad) a.haspad[b] = 1;             // a PAD inside the generated part (reference quirk 2)
     }
     a.front[b] = f + bacc + 1;
     a.rec[slot] = CopyRec{b, best, bacc, f};
@@ -1112,7 +1113,29 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     st->src_positions += (long long)Bc * a.Ls;
     st->width = width;
     if (s_anyfin && width > a.max_len) st->error = 1;
-    const int stop = (nn == 0 || width >= a.max_len) ? 1 : 0;
+    int stop = (nn == 0 || width >= a.max_len) ? 1 : 0;
+    if (!stop) {
+      // Reference quirk 2 (speculative_decoding.py:97,111-115): if some column up to the longest running row's
+      // front is PAD in every running row, the reference under-sizes its padded tensor and the draft scatter
+      // raises.  Only possible when a running row holds a PAD token, so the scan below almost never runs.
+      bool suspect = false;
+      int maxf = 0;
+      for (int i = 0; i < nn; ++i) {
+        const int b = a.act_idx[i];
+        suspect |= (a.haspad[b] != 0);
+        maxf = max(maxf, a.front[b]);
+      }
+      if (suspect) {
+        for (int c = 0; c <= maxf && !stop; ++c) {
+          bool allpad = true;
+          for (int i = 0; i < nn && allpad; ++i) {
+            const int b = a.act_idx[i];
+            if (a.front[b] >= c && a.gen[(size_t)b * a.gen_ld + c] != a.pad) allpad = false;
+          }
+          if (allpad) { st->error = 2; stop = 1; }
+        }
+      }
+    }
     st->stop = stop;
     st->n_active = stop ? 0 : nn;
     st->r_rows = stop ? 0 : nn * a.N;
