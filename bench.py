@@ -214,6 +214,30 @@ def main():
             dt1 = time.perf_counter() - t1
             line["one_batch_at_a_time"] = {"value": len(timed) * a.batch_size / dt1, "unit": "reactions/s",
                                            "identical_to_in_flight_outputs": all(torch.equal(x, y) for x, y in zip(seq, outs))}
+        if os.environ.get("TTX_BENCH_SORTED", "1") == "1":
+            # what length-bucketed batching (the scheduling DESIGN.md §8 item 3 names) would buy on the same reactions:
+            # same sequences, batches formed after sorting by source length; per-reaction outputs are identical
+            order = sorted(range(len(mine) - a.warmup * a.batch_size), key=lambda i: len(mine[a.warmup * a.batch_size + i]))
+            pool = [mine[a.warmup * a.batch_size + i] for i in order]
+            sb = [torch.from_numpy(b).to(dev) for b in batches(pool, a.batch_size)]
+            gs = make_gen(model)
+            gs.generate_many(sb[:a.inflight], in_flight=a.inflight)
+            gs = make_gen(model)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            so = gs.generate_many(sb, in_flight=a.inflight) if a.inflight > 1 else [gs.generate(b) for b in sb]
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t1
+            flat_sorted = torch.cat([o[:, 0, :] for o in so])
+            inv = torch.empty(len(order), dtype=torch.long)
+            inv[torch.tensor(order)] = torch.arange(len(order))
+            resorted = flat_sorted[inv.to(dev)]
+            # a row that is still running when its batch's width reaches max_len stays all-PAD (reference quirk 1), which
+            # depends on the batch it sits in; every row that finished under both groupings must be token-identical
+            both = (resorted == EOS).any(dim=1) & (preds == EOS).any(dim=1)
+            line["length_sorted_batches"] = {"value": len(pool) / dts, "unit": "reactions/s", "model_calls": gs.model_calls_num,
+                                             "rows_finished_in_both": int(both.sum()),
+                                             "of_those_token_identical": int((resorted[both] == preds[both]).all(dim=1).sum())}
         if not a.no_profile:
             # dominant kernel = k_gemm_tn (fp32 MFMA GEMM): HIP events on the launch stream around every launch,
             # same batches, same process, right after the timed region
