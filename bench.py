@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--draft-len", type=int, default=10)
     ap.add_argument("--n-drafts", type=int, default=3)
     ap.add_argument("--max-len", type=int, default=200)
-    ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "2500")))
+    ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "1500")))
     ap.add_argument("--cpu-batches", type=int, default=1, help="batches of the workload timed on the host cores")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("TTX_INFLIGHT", "8")),
                     help="batches decoded concurrently per GPU (1 = the reference's one-batch-at-a-time loop)")
@@ -74,8 +74,9 @@ def log(*a):
 
 def get_weights(train_steps: int, device: str) -> dict:
     path = os.environ.get("TTX_WEIGHTS") or f"/tmp/ttx_synth_mit_{train_steps}.pt"
-    if os.path.exists(path):
-        return torch.load(path, weights_only=True, map_location="cpu")
+    for cand in (path, str(ROOT / ".weights_cache" / f"synth_mit_{train_steps}.pt")):   # caches written by earlier runs
+        if os.path.exists(cand):
+            return torch.load(cand, weights_only=True, map_location="cpu")
     from tools.train_synth import train
     sd = train("mit", steps=train_steps, device=device, verbose=os.environ.get("TTX_BENCH_VERBOSE") == "1")
     try:

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=["c3", "c4"])
     ap.add_argument("--batches", type=int, default=8)
     ap.add_argument("--smart", type=int, default=0)
-    ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "2500")))
+    ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "1500")))
     a = ap.parse_args()
     import translation_transformer_amd as tta
     from tools.synth import SynthReactions, batches, PAD, BOS, EOS, C_TOK, V

@@ -268,6 +268,9 @@ struct ttx_session {
   Buf tok_tgt, mem_pad_tmp;
   // loop
   Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf, dbg_self, dbg_cross, haspad;
+  // tree (beam) decoding
+  Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of, t_len, t_parent, t_parent_draft, t_active;
+  struct { int B = 0, Ls = 0, max_cand = 0, max_len = 0, N = 0, D = 0, Lc = 0, gen_ld = 0, cur = 0, prev_N = 1, prev_D = 0, steps = 0; } tree;
   bool attn_debug = false;
   HostInfo* host_info = nullptr;   // pinned + device-mapped, written by the accept kernels
   hipStream_t own_stream = nullptr; // used by the many-batches driver
@@ -294,7 +297,8 @@ struct ttx_session {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
   ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
-                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad}) all.push_back(b); }
+                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &tk[0], &tk[1], &tv[0], &tv[1],
+                                 &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active}) all.push_back(b); }
 };
 
 static thread_local uint64_t* g_alloc_gen = nullptr;   // alloc_generation of the session being sized
@@ -675,6 +679,10 @@ extern "C" int ttx_make_drafts(ttx_session* s, const int64_t* d_src, int B, int 
 struct StepCtx {
   int B, Ls, N, D, Lc, gen_ld, max_len;
   ttx_gen_params p;
+  const float* kcache = nullptr;   // null: the session's greedy-path caches
+  const float* vcache = nullptr;
+  const int* src_of = nullptr;     // running row -> source row (tree decoding)
+  bool want_argmax = true;
 };
 
 static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) {
@@ -714,7 +722,8 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     AttnArgs a{};
     a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d; a.scale = scale;
     a.tok = s->gen.as<int>(); a.pad = c.pad_token; a.st = dst; a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>();
-    a.kcache = s->kcache.as<float>() + (size_t)l * cache_layer; a.vcache = s->vcache.as<float>() + (size_t)l * cache_layer;
+    a.kcache = (k.kcache ? k.kcache : s->kcache.as<float>()) + (size_t)l * cache_layer;
+    a.vcache = (k.vcache ? k.vcache : s->vcache.as<float>()) + (size_t)l * cache_layer;
     a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D = k.D;
     if (s->attn_debug && l == Ld - 1) a.dbg = s->dbg_self.as<unsigned long long>();
     TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, k.B, H, RPS, kcap, k.N, D1));
@@ -725,6 +734,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     ca.q = q2; ca.ldq = d; ca.k = s->memkv.as<float>() + (size_t)l * 2 * d; ca.v = ca.k + d; ca.ldkv = Ld * 2 * d;
     ca.out = ao; ca.d = d; ca.scale = scale; ca.Lk = k.Ls; ca.key_pad = s->src_valid.as<uint8_t>();
     ca.st = dst; ca.act_idx = s->act_idx.as<int>(); ca.front = s->front.as<int>(); ca.N = k.N; ca.D = k.D;
+    ca.src_of = k.src_of;
     if (s->attn_debug && l == Ld - 1) ca.dbg = s->dbg_cross.as<unsigned long long>();
     TTX_TRY(launch_attn<ATT_STEP_CROSS>(s, st, ca, k.B, H, RPS, k.Ls, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
@@ -734,8 +744,10 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
                     last ? m->p(m->dec_norm_w) : nullptr, last ? m->p(m->dec_norm_b) : nullptr, nullptr, last ? xf : x, m_ptr, Mmax));
   }
   TTX_TRY(launch_gemm(s, st, xf, d, m->p(m->cls_w), d, m->p(m->cls_b), logits, V, m_ptr, Mmax, V, d, false, 0, 0));
-  hipLaunchKernelGGL(k_argmax, dim3(cdiv(Mmax, 4)), dim3(256), 0, st, logits, V, s->pred.as<int>(), m_ptr, Mmax);
-  HIP_TRY(hipGetLastError());
+  if (k.want_argmax) {
+    hipLaunchKernelGGL(k_argmax, dim3(cdiv(Mmax, 4)), dim3(256), 0, st, logits, V, s->pred.as<int>(), m_ptr, Mmax);
+    HIP_TRY(hipGetLastError());
+  }
   return TTX_OK;
 }
 
@@ -1117,6 +1129,103 @@ extern "C" int ttx_greedy_speculative_generate_many(ttx_session** sessions, int 
   // later work on the caller's stream must see the outputs
   (void)hipEventDestroy(ready);
   return rc_final;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tree (beam) decoding: encoder + cross K/V once (begin), then one KV-cached verify step per call.
+extern "C" int ttx_tree_begin(ttx_session* s, const int64_t* d_src, int B, int Ls, int max_cand, int max_len, int n_drafts,
+                              int draft_len, void* stream) {
+  if (!s || !d_src || B <= 0 || Ls <= 1 || max_cand < B || max_len < 1 || n_drafts < 1 || draft_len < 0)
+    return fail(TTX_ERR_INVALID, "bad argument to ttx_tree_begin");
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  if (max_len + draft_len + 2 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len + draft_len exceeds the positional table");
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
+  auto& t = s->tree;
+  t.B = B; t.Ls = Ls; t.max_cand = max_cand; t.max_len = max_len; t.N = n_drafts; t.D = draft_len;
+  t.Lc = max_len + draft_len + 2; t.gen_ld = max_len + draft_len + 2; t.cur = 0; t.prev_N = 1; t.prev_D = 0; t.steps = 0;
+  const size_t Mmax = (size_t)max_cand * step_rps(n_drafts, draft_len);
+  g_alloc_gen = &s->alloc_generation;
+  const uint64_t gen_before = s->alloc_generation;
+  int rc = TTX_OK;
+  auto need = [&](Buf& b, size_t bytes) { if (rc == TTX_OK) rc = ensure(b, bytes, st); };
+  need(s->tok_src, (size_t)B * Ls * 4); need(s->src_valid, (size_t)B * Ls); need(s->memory, (size_t)B * Ls * d * 4);
+  need(s->memkv, (size_t)B * Ls * Ld * 2 * d * 4);
+  need(s->drafts, (size_t)max_cand * n_drafts * std::max(draft_len, 1) * 4);
+  need(s->gen, (size_t)max_cand * t.gen_ld * 4); need(s->front, (size_t)max_cand * 4); need(s->act_idx, (size_t)max_cand * 4);
+  need(s->pred, Mmax * 4); need(s->state, sizeof(DecState)); need(s->logits, Mmax * V * 4);
+  for (int i = 0; i < 2; ++i) { need(s->tk[i], (size_t)Ld * max_cand * t.Lc * d * 4); need(s->tv[i], (size_t)Ld * max_cand * t.Lc * d * 4); }
+  need(s->t_prev_len, (size_t)max_cand * 4); need(s->t_slot_of, (size_t)max_cand * 4); need(s->t_src_of, (size_t)max_cand * 4);
+  need(s->t_len, (size_t)max_cand * 4); need(s->t_parent, (size_t)max_cand * 4); need(s->t_parent_draft, (size_t)max_cand * 4);
+  need(s->t_active, (size_t)max_cand);
+  const size_t Macts = std::max(Mmax, (size_t)B * Ls);
+  if (rc == TTX_OK) rc = ensure_acts(s, st, Macts, 1);
+  need(s->qkv, std::max((size_t)Ld * Mmax, (size_t)B * Ls) * 3 * d * 4);
+  need(s->slab, sizeof(float) * 16 * Macts * d);
+  g_alloc_gen = nullptr;
+  if (s->alloc_generation != gen_before) s->drop_graphs();
+  TTX_TRY(rc);
+  TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
+  TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));
+  return launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv.as<float>(),
+                     Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0);
+}
+
+extern "C" int ttx_tree_step(ttx_session* s, const int64_t* d_cand, int n_cand, int width, const int32_t* d_len,
+                             const int32_t* d_parent, const int32_t* d_parent_draft, const int32_t* d_src_row,
+                             const uint8_t* d_active, const int64_t* d_drafts, int N, int D, float* d_logits, void* stream) {
+  if (!s || !d_cand || !d_len || !d_parent || !d_parent_draft || !d_src_row || !d_active || !d_logits || (!d_drafts && D > 0))
+    return fail(TTX_ERR_INVALID, "null argument to ttx_tree_step");
+  auto& t = s->tree;
+  if (t.B <= 0) return fail(TTX_ERR_INVALID, "ttx_tree_step before ttx_tree_begin");
+  if (n_cand <= 0 || n_cand > t.max_cand || N < 1 || N > t.N || D < 0 || D > t.D || width < 1 || width > t.gen_ld)
+    return fail(TTX_ERR_INVALID, "ttx_tree_step: shape outside what ttx_tree_begin sized");
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
+  const long long cache_seq = (long long)t.Lc * d, cache_layer = (long long)t.max_cand * cache_seq;
+  const int nxt = t.cur ^ 1;
+  // 1. every candidate's cache = its parent's cache + the parent's accepted rows of the previous step
+  if (t.steps > 0) {
+    TreeCacheArgs ca{};
+    ca.len = d_len; ca.parent = d_parent; ca.parent_draft = d_parent_draft; ca.prev_len = s->t_prev_len.as<int>(); ca.active = d_active;
+    ca.k_old = s->tk[t.cur].as<float>(); ca.v_old = s->tv[t.cur].as<float>();
+    ca.k_new = s->tk[nxt].as<float>(); ca.v_new = s->tv[nxt].as<float>();
+    ca.cache_layer_stride = cache_layer; ca.cache_seq_stride = cache_seq;
+    ca.qkv_prev = s->qkv.as<float>();
+    ca.qkv_layer_stride = (long long)t.max_cand * step_rps(t.prev_N, t.prev_D) * 3 * d;   // run_step's layout of the previous call
+    ca.prev_slot_of = s->t_slot_of.as<int>(); ca.prev_N = t.prev_N; ca.prev_D = t.prev_D; ca.d = d;
+    hipLaunchKernelGGL(k_tree_cache, dim3(n_cand, Ld), dim3(256), 0, st, ca);
+    HIP_TRY(hipGetLastError());
+  }
+  t.cur = nxt;
+  // 2. loop state for the verify-step kernels
+  TreePrepArgs pa{};
+  pa.cand = d_cand; pa.width = width; pa.len = d_len; pa.active = d_active; pa.drafts = d_drafts;
+  pa.n_cand = n_cand; pa.N = N; pa.D = D; pa.pad = c.pad_token;
+  pa.gen = s->gen.as<int>(); pa.gen_ld = t.gen_ld; pa.front = s->front.as<int>(); pa.act_idx = s->act_idx.as<int>();
+  pa.drafts32 = s->drafts.as<int>(); pa.st = s->state.as<DecState>();
+  hipLaunchKernelGGL(k_tree_prep, dim3(std::min(64, cdiv(n_cand * t.gen_ld, 256))), dim3(256), 0, st, pa);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tree_slots, dim3(1), dim3(256), 0, st, s->state.as<DecState>(), s->act_idx.as<int>(), s->t_slot_of.as<int>(),
+                     d_len, s->t_prev_len.as<int>(), n_cand);
+  HIP_TRY(hipGetLastError());
+  // 3. the verify step itself (embed, Ld decoder layers on the KV cache, classifier)
+  StepCtx k{};
+  k.B = t.max_cand; k.Ls = t.Ls; k.N = N; k.D = D; k.Lc = t.Lc; k.gen_ld = t.gen_ld; k.max_len = t.max_len;
+  k.kcache = s->tk[t.cur].as<float>(); k.vcache = s->tv[t.cur].as<float>(); k.src_of = d_src_row; k.want_argmax = false;
+  // NOTE: the step kernels lay their rows out with stride max_cand * RPS(N, D) per layer in s->qkv
+  TTX_TRY(run_step(s, st, k, std::min(t.max_len, ((width + 63) / 64) * 64)));
+  // 4. logits of the step rows -> [n_cand, N, D+1, V]
+  hipLaunchKernelGGL(k_tree_logits, dim3(n_cand, N * (D + 1)), dim3(256), 0, st, s->logits.as<float>(), V, s->state.as<DecState>(),
+                     s->act_idx.as<int>(), N, D, d_logits);
+  HIP_TRY(hipGetLastError());
+  t.prev_N = N; t.prev_D = D; t.steps += 1;
+  return TTX_OK;
 }
 
 extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms) {

@@ -486,6 +486,7 @@ struct AttnArgs {
   const int* mem_row;              // FULL_CROSS: decoder row -> memory row (null: identity)
   // step modes
   const DecState* st; const int* act_idx; const int* front;
+  const int* src_of;               // step modes: running row -> source row of the encoder memory (null: identity)
   const float* kcache; const float* vcache; long long cache_seq_stride;  // floats per sequence in the cache
   int gen_ld; int N; int D;
   unsigned long long* dbg;         // diagnostic builds only: per-block phase stamps (100 MHz realtime clock)
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(64) void k_attn(AttnArgs a) {
                 },
                 a.out + (srow0 + q0) * a.d + hd, a.d, a.scale, lds);
     } else {
-      const size_t mrow0 = (size_t)b * a.Lk;
+      const size_t mrow0 = (size_t)(a.src_of ? a.src_of[b] : b) * a.Lk;
       const uint8_t* kv = a.key_pad + mrow0;
       const float* kb = a.k + mrow0 * a.ldkv + hd;
       const float* vb = a.v + mrow0 * a.ldkv + hd;
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                  a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, lds, a2_qcap(RPS),
                  a.dbg ? a.dbg + 8 * (size_t)(blockIdx.x * gridDim.y + blockIdx.y) : nullptr);
     } else {
-      const size_t mrow0 = (size_t)b * a.Lk;
+      const size_t mrow0 = (size_t)(a.src_of ? a.src_of[b] : b) * a.Lk;
       const uint8_t* kv = a.key_pad + mrow0;
       const float* kb = a.k + mrow0 * a.ldkv + hd;
       const float* vb = a.v + mrow0 * a.ldkv + hd;
@@ -1215,6 +1216,101 @@ __global__ __launch_bounds__(256) void k_kvcopy(KvCopyArgs a) {
     *reinterpret_cast<float4*>(kc + (size_t)j * a.d + c) = *reinterpret_cast<const float4*>(p + a.d + c);
     *reinterpret_cast<float4*>(vc + (size_t)j * a.d + c) = *reinterpret_cast<const float4*>(p + 2 * a.d + c);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tree (beam) decoding with a per-candidate KV cache: SURVEY.md §2.3 K12-K14's decoder side.  A "candidate" is one
+// hypothesis row (n_best per source); its cache is rebuilt every step from its parent's cache plus the parent's
+// accepted step rows, then the same verify-step kernels run with candidate = running row.
+struct TreePrepArgs {
+  const int64_t* cand; int width;        // [n_cand, width] tokens, left-aligned, PAD after
+  const int* len;                        // [n_cand] real tokens per candidate (last one = front)
+  const uint8_t* active;                 // [n_cand]
+  const int64_t* drafts;                 // [n_cand, N, D]
+  int n_cand, N, D, pad;
+  int* gen; int gen_ld; int* front; int* act_idx; int* drafts32; DecState* st;
+};
+
+__global__ __launch_bounds__(256) void k_tree_prep(TreePrepArgs a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int i = tid; i < a.n_cand * a.gen_ld; i += nth) {
+    const int c = i / a.gen_ld, col = i % a.gen_ld;
+    a.gen[i] = col < a.width ? (int)a.cand[(size_t)c * a.width + col] : a.pad;
+  }
+  for (int i = tid; i < a.n_cand * a.N * a.D; i += nth) a.drafts32[i] = (int)a.drafts[i];
+  for (int i = tid; i < a.n_cand; i += nth) a.front[i] = a.len[i] - 1;
+  if (tid == 0) {
+    int n = 0;
+    for (int c = 0; c < a.n_cand; ++c)
+      if (a.active[c]) a.act_idx[n++] = c;
+    DecState s;
+    s.n_active = n; s.r_rows = n * a.N; s.m_rows = n * step_rps(a.N, a.D);
+    s.stop = 0; s.width = a.width; s.steps = 0; s.error = 0; s.n_copy = 0;
+    s.accepted = s.produced = s.verified_positions = s.kv_prefix_positions = s.src_positions = 0;
+    *a.st = s;
+  }
+}
+
+// new_cache[c][0 .. len_c-2] = parent's cache [0 .. len_p-2] ++ parent's front row ++ parent's accepted draft rows.
+struct TreeCacheArgs {
+  const int* len; const int* parent; const int* parent_draft; const int* prev_len; const uint8_t* active;
+  const float* k_old; const float* v_old; float* k_new; float* v_new;
+  long long cache_layer_stride, cache_seq_stride;      // floats
+  const float* qkv_prev; long long qkv_layer_stride;    // previous step's packed QKV rows, [Ld][M][3d]
+  const int* prev_slot_of;                               // previous step: candidate -> slot in its compact active list (-1: inactive)
+  int prev_N, prev_D, d;
+};
+
+__global__ __launch_bounds__(256) void k_tree_cache(TreeCacheArgs a) {
+  const int c = blockIdx.x, l = blockIdx.y;
+  if (!a.active[c]) return;
+  const int p = a.parent[c];
+  if (p < 0) return;                                     // fresh candidate (<BOS> only): nothing cached yet
+  const int lc = a.len[c], lp = a.prev_len[p];
+  const int per_row = a.d / 4;
+  const float* ko = a.k_old + (size_t)l * a.cache_layer_stride + (size_t)p * a.cache_seq_stride;
+  const float* vo = a.v_old + (size_t)l * a.cache_layer_stride + (size_t)p * a.cache_seq_stride;
+  float* kn = a.k_new + (size_t)l * a.cache_layer_stride + (size_t)c * a.cache_seq_stride;
+  float* vn = a.v_new + (size_t)l * a.cache_layer_stride + (size_t)c * a.cache_seq_stride;
+  const int n_old = lp - 1;                              // positions the parent had cached
+  for (int e = threadIdx.x; e < n_old * per_row; e += blockDim.x) {
+    reinterpret_cast<float4*>(kn)[e] = reinterpret_cast<const float4*>(ko)[e];
+    reinterpret_cast<float4*>(vn)[e] = reinterpret_cast<const float4*>(vo)[e];
+  }
+  const int n_new = (lc - 1) - n_old;                    // parent's front row + accepted draft rows
+  const int slot = a.prev_slot_of[p];
+  if (n_new <= 0 || slot < 0) return;
+  const int RPS = step_rps(a.prev_N, a.prev_D);
+  const float* src = a.qkv_prev + (size_t)l * a.qkv_layer_stride + ((size_t)slot * RPS) * 3 * a.d;
+  const int dp = a.parent_draft[c];
+  for (int e = threadIdx.x; e < n_new * per_row; e += blockDim.x) {
+    const int j = e / per_row, col = (e % per_row) * 4;
+    const int srow = (j == 0) ? 0 : 1 + dp * a.prev_D + (j - 1);
+    const float* q = src + (size_t)srow * 3 * a.d;
+    *reinterpret_cast<float4*>(kn + (size_t)(n_old + j) * a.d + col) = *reinterpret_cast<const float4*>(q + a.d + col);
+    *reinterpret_cast<float4*>(vn + (size_t)(n_old + j) * a.d + col) = *reinterpret_cast<const float4*>(q + 2 * a.d + col);
+  }
+}
+
+// remember which compact slot every candidate had in this step (the next step's cache build needs it)
+__global__ void k_tree_slots(const DecState* st, const int* act_idx, int* slot_of, const int* len, int* prev_len, int n_cand) {
+  for (int i = threadIdx.x; i < n_cand; i += blockDim.x) { slot_of[i] = -1; prev_len[i] = len[i]; }   // single block
+  __syncthreads();
+  for (int s = threadIdx.x; s < st->n_active; s += blockDim.x) slot_of[act_idx[s]] = s;
+}
+
+// logits of the step rows -> [n_cand, N, D+1, V] (position 0 of every draft is the shared front row)
+__global__ __launch_bounds__(256) void k_tree_logits(const float* logits, int V, const DecState* st, const int* act_idx, int N, int D,
+                                                     float* out) {
+  const int slot = blockIdx.x;
+  if (slot >= st->n_active) return;
+  const int c = act_idx[slot];
+  const int RPS = step_rps(N, D), D1 = D + 1;
+  const int n = blockIdx.y / D1, j = blockIdx.y % D1;
+  const int srow = (j == 0) ? 0 : 1 + n * D + (j - 1);
+  const float* src = logits + ((size_t)slot * RPS + srow) * V;
+  float* dst = out + (((size_t)c * N + n) * D1 + j) * V;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) dst[v] = src[v];
 }
 
 }  // namespace ttx

@@ -5,11 +5,12 @@ HIP library.  ``model`` must be a ``NativeTransformer``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from . import _native as N
-from .model import NativeTransformer
+from .model import NativeTransformer, TreeDecoder
 
 
 def _need_native(model) -> NativeTransformer:
@@ -108,6 +109,11 @@ def _decode(model, tgt, memory, mask, rows):
     return model.decode_tgt(tgt, memory[rows], memory_pad_mask=mask[rows])
 
 
+def _use_kv_cache(model) -> bool:
+    """Beam paths on the HIP model decode through the per-candidate KV cache (ttx_tree_*) unless TTX_BEAM_KV_CACHE=0."""
+    return isinstance(model, NativeTransformer) and os.environ.get("TTX_BEAM_KV_CACHE", "1") != "0"
+
+
 def _drafts(model, src, draft_len, n_drafts, lo, hi, eos, pad, repl):
     if isinstance(model, NativeTransformer):
         return model.make_drafts(src, draft_len, n_drafts, lo, hi, eos, pad, repl)
@@ -164,7 +170,13 @@ class _BeamSearchHost:
         src = src.to(dev)
         B = src.size(0)
         pad_col = m.src_pad_token_i                                   # standard_decoding.py:135
-        first = m(src, torch.full((B, 1), self.bos_token, dtype=src.dtype, device=dev))   # :102
+        tree = TreeDecoder(m, src, B * K, self.max_len, 1, 0) if _use_kv_cache(m) else None
+        y0 = torch.full((B, 1), self.bos_token, dtype=src.dtype, device=dev)
+        if tree is not None:
+            ones = torch.ones(B, dtype=torch.int32, device=dev)
+            first = tree.step(y0, ones, -ones, 0 * ones, torch.arange(B, device=dev), ones.bool(), None, 1, 0)[:, 0]
+        else:
+            first = m(src, y0)                                        # :102
         self.b_sz += B
         self.model_calls_num += 1
         self.given_tokens += int((src != pad_col).sum())
@@ -173,20 +185,28 @@ class _BeamSearchHost:
         y = torch.cat([torch.full((B * K, 1), self.bos_token, dtype=src.dtype, device=dev), tok.reshape(-1, 1)], dim=1)
         # the reference re-encodes the source once per beam (:120-124); the rows are identical, so the HIP path
         # encodes once and lets the K beams of a source share that memory row
-        mask = src == pad_col
-        memory = m.encode_src(src, mask)
         owner = torch.arange(B, device=dev).repeat_interleave(K)
+        if tree is None:
+            mask = src == pad_col
+            memory = m.encode_src(src, mask)
+        prev_parent = owner.clone()                                   # row (b,k) extends the <BOS> row of source b
         for _ in range(self.max_len - 2):
             alive = ~((y == self.eos_token).any(dim=1))
             self.b_sz += int(alive.sum())
             step = torch.zeros((B * K, V), dtype=torch.float32, device=dev)
             step[:, pad_col] = 35.0
-            step[alive] = _decode(m, y[alive], memory, mask, owner[alive])[:, -1, :]
+            if tree is not None:
+                length = torch.full((B * K,), y.size(1), dtype=torch.int32, device=dev)
+                out = tree.step(y, length, prev_parent, torch.zeros_like(length), owner, alive, None, 1, 0)[:, 0, 0]
+                step[alive] = out[alive]
+            else:
+                step[alive] = _decode(m, y[alive], memory, mask, owner[alive])[:, -1, :]
             self.model_calls_num += 1
             total = (score.unsqueeze(-1) + torch.log(torch.softmax(step, dim=-1)).reshape(B, K, V)).reshape(B, K * V)
             score, flat = total.topk(K, dim=-1, sorted=True)
             parent = torch.div(flat, V, rounding_mode="floor") + torch.arange(B, device=dev).unsqueeze(1) * K
-            y = torch.cat([y[parent.reshape(-1)], (flat % V).reshape(-1, 1)], dim=1)
+            prev_parent = parent.reshape(-1)
+            y = torch.cat([y[prev_parent], (flat % V).reshape(-1, 1)], dim=1)
             if bool((y == self.eos_token).any(dim=1).all()):
                 break
         return y.reshape(B, K, -1)
@@ -271,6 +291,10 @@ class _BeamSearchSpeculativeHost:
 
         cand = torch.full((B, 1), BOS, dtype=torch.int64, device=dev)
         logp = torch.zeros(B, dtype=torch.float32, device=dev)
+        n_slots = self.requested_drafts_num if smart else drafts_all.size(1)
+        kvdec = TreeDecoder(m, src, B * K, self.max_len, n_slots, dl) if _use_kv_cache(m) else None
+        prev_parent = torch.full((B,), -1, dtype=torch.int64, device=dev)
+        prev_pdraft = torch.zeros(B, dtype=torch.int64, device=dev)
         empty_cols, after_last = 0, 1
         room = self.max_len - after_last - 1
         steps = 0
@@ -310,7 +334,27 @@ class _BeamSearchSpeculativeHost:
             logits = torch.zeros((row_c.numel(), dl + 1, V), dtype=torch.float32, device=dev)
             logits[:, :, PAD] = 35.0
             self.b_sz += int(running.sum())
-            if bool(running.any()):
+            if kvdec is not None:
+                # the cache assumes left-aligned rows; a running row with a PAD before its last real token (the model
+                # sampled PAD before EOS) makes the reference overwrite that PAD with a draft: leave the cached path
+                irregular = (pads.cummax(dim=-1).values & ~pads).any(dim=-1) & ~((cand == EOS).any(dim=-1))
+                if bool(irregular.any()):
+                    kvdec = None
+            if smart:
+                start = per_cand.cumsum(0) - per_cand
+                row_slot = torch.arange(row_c.numel(), device=dev) - start[row_c]
+            else:
+                row_slot = torch.arange(row_c.numel(), device=dev) % n_slots
+            if kvdec is not None:
+                if smart:                                                       # unused slots repeat the first draft
+                    slots = row_d[start].unsqueeze(1).repeat(1, n_slots, 1)
+                    slots[row_c, row_slot] = row_d
+                else:
+                    slots = row_d.reshape(n_cand, n_slots, dl)
+                out = kvdec.step(cand, (~pads).sum(-1), prev_parent, prev_pdraft, owner, ~((cand == EOS).any(dim=-1)), slots,
+                                n_slots, dl)
+                logits[running] = out[row_c[running], row_slot[running]]
+            elif bool(running.any()):
                 out = _decode(m, inputs[running], memory, mask, owner[row_c[running]])
                 look = slot[row_c[running]]
                 look = look | look.roll(-1, dims=1)
@@ -354,6 +398,8 @@ class _BeamSearchSpeculativeHost:
             mark[(cand[lc] == EOS).any(dim=1)] = -1
 
             top_s, top_i = _ragged_topk(score, per_src, K, float("-inf"))
+            prev_parent = lc[top_i]                                             # candidate of this step each survivor extends
+            prev_pdraft = row_slot[best_row][prev_parent]                       # ... and the draft slot it kept tokens from
             cand = roots[top_i]
             mark = mark[top_i]
             mark = mark[mark >= 0]
