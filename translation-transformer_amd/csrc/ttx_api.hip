@@ -272,6 +272,9 @@ struct ttx_session {
   Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of, t_len, t_parent, t_parent_draft, t_active;
   struct { int B = 0, Ls = 0, max_cand = 0, max_len = 0, N = 0, D = 0, Lc = 0, gen_ld = 0, cur = 0, prev_N = 1, prev_D = 0, steps = 0; } tree;
   bool attn_debug = false;
+  bool gemm_debug = false;
+  int gemm_debug_n = 0;
+  Buf dbg_gemm;
   HostInfo* host_info = nullptr;   // pinned + device-mapped, written by the accept kernels
   hipStream_t own_stream = nullptr; // used by the many-batches driver
   uint64_t alloc_generation = 0;   // bumped whenever a workspace buffer moves (captured graphs hold raw pointers)
@@ -286,6 +289,7 @@ struct ttx_session {
   // profiling of the GEMM launches (bench.py roofline)
   bool profile = false;
   bool gemm_v1 = false, attn_v1 = false;
+  int gemm3_max_wg = 300;          // launches with at most this many 64x64 workgroups use the 32x32 kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double prof_ms = 0;
@@ -298,7 +302,7 @@ struct ttx_session {
   ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
                                  &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &tk[0], &tk[1], &tv[0], &tv[1],
-                                 &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active}) all.push_back(b); }
+                                 &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active, &dbg_gemm}) all.push_back(b); }
 };
 
 static thread_local uint64_t* g_alloc_gen = nullptr;   // alloc_generation of the session being sized
@@ -338,9 +342,15 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   const char* pf = getenv("TTX_PROFILE_GEMM");
   s->profile = pf && pf[0] == '1';
   s->gemm_v1 = getenv("TTX_GEMM_V1") != nullptr;
+  if (const char* g3 = getenv("TTX_GEMM3")) {
+    if (!strcmp(g3, "all")) s->gemm3_max_wg = 1 << 30;
+    else if (!strcmp(g3, "none")) s->gemm3_max_wg = -1;
+    else s->gemm3_max_wg = atoi(g3);
+  }
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
+  if (const char* gd = getenv("TTX_GEMM_DEBUG")) { s->gemm_debug = true; s->gemm_debug_n = atoi(gd); }
   *out = s;
   return TTX_OK;
 }
@@ -385,6 +395,9 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
   const int S = splits > 0 ? splits : 1;
   a.k_per_split = K / S;
   a.slab_stride = slab_stride;
+  a.dbg = nullptr;
+  if (s->gemm_debug && s->dbg_gemm.p && (size_t)cdiv(N, 64) * cdiv(Mmax, 64) * S * 64 <= s->dbg_gemm.cap && N == s->gemm_debug_n && !a.raw)
+    a.dbg = s->dbg_gemm.as<unsigned long long>();
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (s->profile) {
     if (s->ev_used == s->ev_pool.size()) {
@@ -398,7 +411,20 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
     s->ev_used++;
     HIP_TRY(hipEventRecord(e0, st));
   }
-  if (Mmax <= 32) {
+  // Kernel choice: the 64x64 deep-prefetch kernel when the launch has workgroups to spare; the 32x32
+  // operands-in-registers kernel (4x the workgroups) when it does not.  TTX_GEMM3=all|none|<max 64x64 workgroups>.
+  const int wg64 = cdiv(N, 64) * cdiv(Mmax, 64) * S;
+  const bool k3_ok = (a.k_per_split % 32 == 0) && (a.k_per_split / 4 == 16 || (a.k_per_split / 4) % 64 == 0);
+  const bool use3 = k3_ok && !s->gemm_v1 && wg64 <= s->gemm3_max_wg;
+  if (use3) {
+    dim3 grid(cdiv(N, 32), cdiv(Mmax, 32), S);
+    switch (a.k_per_split / 4) {
+      case 16: hipLaunchKernelGGL((k_gemm3<16>), grid, dim3(256), 0, st, a); break;
+      case 64: hipLaunchKernelGGL((k_gemm3<64>), grid, dim3(256), 0, st, a); break;
+      case 128: hipLaunchKernelGGL((k_gemm3<128>), grid, dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((k_gemm3<0>), grid, dim3(256), 0, st, a); break;
+    }
+  } else if (Mmax <= 32) {
     dim3 grid(cdiv(N, 128), cdiv(Mmax, 32), S);
     hipLaunchKernelGGL((k_gemm_tn<1, 4>), grid, dim3(256), 0, st, a);
   } else if ((a.k_per_split == 64 || a.k_per_split == 128 || a.k_per_split % 256 == 0) && !s->gemm_v1) {
@@ -830,6 +856,10 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   TTX_TRY(ensure(s->state, sizeof(DecState), st));
   TTX_TRY(ensure(s->logits, Mmax * V * 4, st));
   TTX_TRY(ensure(s->outbuf, (size_t)B * max_len * 8, st));
+  if (s->gemm_debug) {
+    TTX_TRY(ensure(s->dbg_gemm, (size_t)64 * 4096, st));
+    HIP_TRY(hipMemsetAsync(s->dbg_gemm.p, 0, (size_t)64 * 4096, st));
+  }
   if (s->attn_debug) {
     TTX_TRY(ensure(s->dbg_self, (size_t)B * c.num_heads * 8 * 8, st));
     TTX_TRY(ensure(s->dbg_cross, (size_t)B * c.num_heads * 8 * 8, st));
@@ -986,6 +1016,27 @@ static int gen_finish_collect(GenJob& j) {
         if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) acc += ms;
       }
       s->prof_empty_pair_ms = acc / 64.0;
+    }
+  }
+  if (s->gemm_debug && s->dbg_gemm.p) {
+    // diagnostic: phases of the workgroups of the last GEMM launch with N == TTX_GEMM_DEBUG
+    // (stamps: 0 start, 1 row count known, 2 first K tile staged, 3 MFMA loop done, 4 stores drained)
+    std::vector<unsigned long long> h(8 * 4096);
+    if (hipMemcpy(h.data(), s->dbg_gemm.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      double acc[4] = {0, 0, 0, 0};
+      unsigned long long first = ~0ull, last = 0;
+      int n = 0;
+      for (int i = 0; i < 4096; ++i) {
+        const unsigned long long* q = &h[(size_t)i * 8];
+        if (!q[0] || !q[4]) continue;
+        for (int ph = 0; ph < 4; ++ph) acc[ph] += (double)(q[ph + 1] - q[ph]) * 0.01;
+        first = std::min(first, q[0]);
+        last = std::max(last, q[4]);
+        ++n;
+      }
+      if (n)
+        fprintf(stderr, "[ttx gemm debug] N=%d workgroups=%d  m_ptr=%.2f stage=%.2f mfma=%.2f store=%.2f us; first start -> last end %.2f us\n",
+                s->gemm_debug_n, n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, (double)(last - first) * 0.01);
     }
   }
   if (s->attn_debug) {

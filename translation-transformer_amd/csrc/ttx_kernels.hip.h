@@ -54,6 +54,7 @@ struct GemmArgs {
   int relu;                  // epilogue
   int raw;                   // 1: write un-biased partial sums to slab blockIdx.z
   long long slab_stride;     // floats between slabs
+  unsigned long long* dbg;   // diagnostic builds only: per-workgroup phase stamps (100 MHz realtime clock)
 };
 
 template <int WGM, int WGN>
@@ -205,9 +206,13 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float As[TTX_G2_BUFS][BM * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[TTX_G2_BUFS][BN * LDT];
 
+  unsigned long long* dbg = a.dbg ? a.dbg + 8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
+#define TTX_GSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  TTX_GSTAMP(0);
   const int M = a.m_ptr ? *a.m_ptr : a.M;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   if (m0 >= M) return;
+  TTX_GSTAMP(1);
   const int kbeg = blockIdx.z * a.k_per_split;
   const int kend = min(a.K, kbeg + a.k_per_split);
   const int ntiles = (kend - kbeg) / BK;
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
       g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
       if constexpr (NT == 0) f0 = g2_load(p, min(base + RING, last) * BK);      // clamped: branch-free refill
       __syncthreads();
+      if (base == 0) TTX_GSTAMP(2);
       g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
       if (TTX_G2_BUFS == 1) __syncthreads();
       g2_store<LDT>(f1, As[TTX_G2_BUFS - 1], Bs[TTX_G2_BUFS - 1], lr, lc);
@@ -288,6 +294,7 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
     }
   }
 
+  TTX_GSTAMP(3);
   float* Y = a.Y + (a.raw ? (size_t)blockIdx.z * a.slab_stride : 0);
   const int col = n0 + wn * 32 + r;
   // all values are finished before the first (predicated) store: a pending load inside the store
@@ -304,6 +311,83 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
     for (int v = 0; v < 16; ++v) {
       const int dr = (v & 3) + 8 * (v >> 2);
       if (dr < rows_left) yp[(size_t)dr * a.ldy] = val[v];
+    }
+  }
+  if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TTX_GSTAMP(4); }
+#undef TTX_GSTAMP
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM v3 for launches that are short of workgroups: a 32x32 output tile per workgroup, its K range split
+// over the 4 waves, MFMA operands loaded straight from global memory into the registers the MFMA reads
+// (lane (r,h) owns row r / column r and the k's 8g+4h..8g+4h+3, which is exactly one float4 per 8 k's) — no
+// LDS staging, no barrier before the math; the four partial tiles meet in LDS (16.5 KB) and leave as
+// whole 128-B rows.  4x the workgroups of the 64x64 kernel and many of them resident per CU.
+template <int KW>   // k's per wave (K range of the workgroup / 4): 16, 64 or 128; 0 = runtime loop in steps of 64
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_gemm3(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float part[4][32 * 33];
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  if (m0 >= M) return;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int kw = (KW > 0) ? KW : a.k_per_split / 4;
+  const int kbeg = blockIdx.z * a.k_per_split + wave * kw;
+  const float* xp = a.X + (size_t)min(m0 + r, M - 1) * a.ldx + kbeg + 4 * h;
+  const float* wp = a.W + (size_t)min(n0 + r, a.N - 1) * a.ldw + kbeg + 4 * h;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  constexpr int CH = (KW > 0 && KW < 64) ? KW : 64;      // k's requested at once per wave
+  for (int k0 = 0; k0 < kw; k0 += CH) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 av[CH / 8], bv[CH / 8];
+#pragma unroll
+    for (int g = 0; g < CH / 8; ++g) {
+      av[g] = *reinterpret_cast<const f32x4*>(xp + k0 + 8 * g);
+      bv[g] = *reinterpret_cast<const f32x4*>(wp + k0 + 8 * g);
+    }
+    // all requests of the chunk go out before the first MFMA (the empty asm reads every destination register;
+    // otherwise the scheduler pairs each load with its MFMAs and the wave eats one memory latency per pair)
+    if constexpr (CH == 64)
+      asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]),
+                        "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]));
+    else
+      asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
+#pragma unroll
+    for (int g = 0; g < CH / 8; ++g) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].x, bv[g].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].y, bv[g].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].z, bv[g].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].w, bv[g].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 16; ++v) part[wave][((v & 3) + 8 * (v >> 2) + 4 * h) * 33 + r] = acc[v];
+  __syncthreads();
+  // 256 threads -> 32 rows x 32 columns, 4 values each along a row (one 128-B row per 8 threads)
+  const int row = t >> 3, c0 = (t & 7) * 4;
+  float4 o;
+  float* op = &o.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = row * 33 + c0 + i;
+    op[i] = part[0][e] + part[1][e] + part[2][e] + part[3][e];
+  }
+  const int grow = m0 + row, gcol = n0 + c0;
+  if (grow < M && gcol < a.N) {
+    float* Y = a.Y + (a.raw ? (size_t)blockIdx.z * a.slab_stride : 0) + (size_t)grow * a.ldy + gcol;
+    const float lo = a.relu ? 0.f : -INFINITY;
+    if (gcol + 3 < a.N && (a.ldy & 3) == 0) {
+      float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!a.raw && a.bias) bb = *reinterpret_cast<const float4*>(a.bias + gcol);
+      o.x = fmaxf(o.x + bb.x, lo); o.y = fmaxf(o.y + bb.y, lo); o.z = fmaxf(o.z + bb.z, lo); o.w = fmaxf(o.w + bb.w, lo);
+      *reinterpret_cast<float4*>(Y) = o;
+    } else {
+      for (int i = 0; i < 4 && gcol + i < a.N; ++i) {
+        const float bb = (!a.raw && a.bias) ? a.bias[gcol + i] : 0.f;
+        Y[i] = fmaxf(op[i] + bb, lo);
+      }
     }
   }
 }
