@@ -289,7 +289,7 @@ struct ttx_session {
   // profiling of the GEMM launches (bench.py roofline)
   bool profile = false;
   bool gemm_v1 = false, attn_v1 = false;
-  int gemm3_max_wg = 300;          // launches with at most this many 64x64 workgroups use the 32x32 kernel
+  int gemm3_max_n = 768;           // step GEMMs at most this wide use the 32x32 kernel (k_gemm3)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double prof_ms = 0;
@@ -342,11 +342,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   const char* pf = getenv("TTX_PROFILE_GEMM");
   s->profile = pf && pf[0] == '1';
   s->gemm_v1 = getenv("TTX_GEMM_V1") != nullptr;
-  if (const char* g3 = getenv("TTX_GEMM3")) {
-    if (!strcmp(g3, "all")) s->gemm3_max_wg = 1 << 30;
-    else if (!strcmp(g3, "none")) s->gemm3_max_wg = -1;
-    else s->gemm3_max_wg = atoi(g3);
-  }
+  if (const char* g3 = getenv("TTX_GEMM3_MAX_N")) s->gemm3_max_n = atoi(g3);
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
@@ -377,10 +373,21 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
 
 // ------------------------------------------------------------------------------------------------
 // Launch helpers
-static int choose_splits(int Mmax, int N, int K) {
-  const int tiles = cdiv(Mmax, 64) * cdiv(N, 64);
-  int S = 1;
-  while (tiles * S < 384 && K / (S * 2) >= 64 && (K % (S * 2 * 32)) == 0 && S < 16) S *= 2;
+// Kernel and split-K choice depend only on (N, K) and on whether the launch belongs to a verify step (M <= a few
+// thousand rows, read from the device) or to a bulk pass (encoder, full-prefix decoder, cross K/V) — never on the
+// row count, so a sequence's arithmetic (summation order) is the same whatever batch it sits in.
+static bool use_gemm3(const ttx_session* s, bool step, int N, int K, int k_per_split) {
+  const int kw4 = k_per_split / 4;
+  const bool ok = (k_per_split % 32 == 0) && (kw4 == 16 || kw4 == 64 || (kw4 % 128) == 0);
+  (void)K;
+  return step && ok && !s->gemm_v1 && N <= s->gemm3_max_n;
+}
+
+static int choose_splits(const ttx_session* s, bool step, int N, int K) {
+  if (!step) return 1;
+  if (N <= s->gemm3_max_n && !s->gemm_v1) return (K >= 2048 && K % 1024 == 0) ? 2 : 1;   // k_gemm3: K already split over 4 waves
+  int S = 1;                                                                                // k_gemm2: 64-wide tiles of a d-wide output
+  while (S < 8 && K / (S * 2) >= 64 && (K % (S * 2 * 64)) == 0 && cdiv(N, 64) * S < 32) S *= 2;
   return S;
 }
 
@@ -411,12 +418,10 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
     s->ev_used++;
     HIP_TRY(hipEventRecord(e0, st));
   }
-  // Kernel choice: the 64x64 deep-prefetch kernel when the launch has workgroups to spare; the 32x32
-  // operands-in-registers kernel (4x the workgroups) when it does not.  TTX_GEMM3=all|none|<max 64x64 workgroups>.
-  const int wg64 = cdiv(N, 64) * cdiv(Mmax, 64) * S;
-  const bool k3_ok = (a.k_per_split % 32 == 0) && (a.k_per_split / 4 == 16 || (a.k_per_split / 4) % 64 == 0);
-  const bool use3 = k3_ok && !s->gemm_v1 && wg64 <= s->gemm3_max_wg;
-  if (use3) {
+  // Kernel choice (see use_gemm3 / choose_splits): 32x32 operands-in-registers kernel for the narrow step GEMMs,
+  // 64x64 deep-prefetch kernel otherwise, the 32-deep generic kernel when K is not a multiple of 64.
+  const bool step = (m_ptr != nullptr);
+  if (use_gemm3(s, step, N, K, a.k_per_split)) {
     dim3 grid(cdiv(N, 32), cdiv(Mmax, 32), S);
     switch (a.k_per_split / 4) {
       case 16: hipLaunchKernelGGL((k_gemm3<16>), grid, dim3(256), 0, st, a); break;
@@ -424,9 +429,6 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
       case 128: hipLaunchKernelGGL((k_gemm3<128>), grid, dim3(256), 0, st, a); break;
       default: hipLaunchKernelGGL((k_gemm3<0>), grid, dim3(256), 0, st, a); break;
     }
-  } else if (Mmax <= 32) {
-    dim3 grid(cdiv(N, 128), cdiv(Mmax, 32), S);
-    hipLaunchKernelGGL((k_gemm_tn<1, 4>), grid, dim3(256), 0, st, a);
   } else if ((a.k_per_split == 64 || a.k_per_split == 128 || a.k_per_split % 256 == 0) && !s->gemm_v1) {
     dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
     switch (a.k_per_split) {
@@ -507,7 +509,7 @@ static int gemm_ln(ttx_session* s, hipStream_t st, const float* X, int ldx, int 
                    const float* resid, const float* g1, const float* b1, const float* g2, const float* b2,
                    const uint8_t* row_valid, float* Y, const int* m_ptr, int Mmax) {
   const int d = s->m->cfg.embedding_dim;
-  const int S = choose_splits(Mmax, d, K);
+  const int S = choose_splits(s, m_ptr != nullptr, d, K);
   const long long stride = (long long)Mmax * d;
   TTX_TRY(ensure(s->slab, sizeof(float) * (size_t)S * stride, st));
   TTX_TRY(launch_gemm(s, st, X, ldx, W, K, nullptr, s->slab.as<float>(), d, m_ptr, Mmax, d, K, false, S, stride));

@@ -339,27 +339,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   constexpr int CH = (KW > 0 && KW < 64) ? KW : 64;      // k's requested at once per wave
-  for (int k0 = 0; k0 < kw; k0 += CH) {
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 av[CH / 8], bv[CH / 8];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  auto load = [&](f32x4 (&av)[CH / 8], f32x4 (&bv)[CH / 8], int k0) {
 #pragma unroll
     for (int g = 0; g < CH / 8; ++g) {
       av[g] = *reinterpret_cast<const f32x4*>(xp + k0 + 8 * g);
       bv[g] = *reinterpret_cast<const f32x4*>(wp + k0 + 8 * g);
     }
-    // all requests of the chunk go out before the first MFMA (the empty asm reads every destination register;
-    // otherwise the scheduler pairs each load with its MFMAs and the wave eats one memory latency per pair)
+  };
+  // The empty asm reads every destination register of a chunk: all of its requests are out before the first MFMA
+  // (otherwise the scheduler pairs each load with its MFMAs and the wave eats one memory latency per pair).
+  auto pin = [&](f32x4 (&av)[CH / 8], f32x4 (&bv)[CH / 8]) {
     if constexpr (CH == 64)
       asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]),
                         "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]));
     else
       asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
+  };
+  auto mma = [&](const f32x4 (&av)[CH / 8], const f32x4 (&bv)[CH / 8]) {
 #pragma unroll
     for (int g = 0; g < CH / 8; ++g) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].x, bv[g].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].y, bv[g].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].z, bv[g].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].w, bv[g].w, acc, 0, 0, 0);
+    }
+  };
+  if constexpr (KW > 0 && KW <= 64) {
+    f32x4 a0[CH / 8], b0[CH / 8];
+    load(a0, b0, 0);
+    pin(a0, b0);
+    mma(a0, b0);
+  } else {
+    // two chunks in flight: chunk i+1 is requested before chunk i is consumed (kw is a multiple of 128 here)
+    f32x4 a0[CH / 8], b0[CH / 8], a1[CH / 8], b1[CH / 8];
+    load(a0, b0, 0);
+    for (int k0 = 0; k0 < kw; k0 += 2 * CH) {
+      load(a1, b1, k0 + CH);
+      pin(a0, b0);
+      mma(a0, b0);
+      if (k0 + 2 * CH < kw) load(a0, b0, k0 + 2 * CH);
+      pin(a1, b1);
+      mma(a1, b1);
     }
   }
 #pragma unroll
@@ -724,7 +745,9 @@ __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq,
   if (qcap > A2_MT) qv1 = *reinterpret_cast<const f32x4*>(q + (size_t)min(lr + 32, nq - 1) * ldq + lc);
   constexpr int A2_U = 8;                            // passes of 32 keys in flight
   // V never touches LDS: in O = P·V lane (dh, h) needs V[key][dh] for its wave's keys only, so each wave keeps its
-  // nkp/4 value rows in registers (requested here, consumed after the softmax)
+  // nkp/4 value rows in registers (requested here, consumed after the softmax).  Wave w owns the 8-key groups
+  // w, w+4, w+8, ...: a fixed interleave, so the order in which a row's keys are summed does not depend on how far
+  // the batch's padding extends (masked keys add exact zeros) — results are the same in any batch.
   const int kq = nkp / 4;
   float vr[A2_VSTEPS][4];
   for (int k0 = 0; k0 < nkp; k0 += 32 * A2_U) {
@@ -744,7 +767,7 @@ __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq,
           for (int jj = 0; jj < 4; ++jj) {
             const float* kp;
             const float* vp;
-            keyptr(min(wave * kq + si * 8 + 4 * h + jj, nk - 1), kp, vp);
+            keyptr(min((wave + 4 * si) * 8 + 4 * h + jj, nk - 1), kp, vp);
             vr[si][jj] = vp[r];
           }
         }
@@ -832,11 +855,11 @@ __device__ __forceinline__ void attn2_core(const float* __restrict__ q, int ldq,
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-      const float* prow = S + (size_t)r * lds_s + 4 * h + wave * kq;
+      const float* prow = S + (size_t)r * lds_s + 4 * h + wave * 8;
 #pragma unroll
       for (int si = 0; si < A2_VSTEPS; ++si) {
         if (si * 8 < kq) {
-          const float4 pv = *reinterpret_cast<const float4*>(prow + si * 8);
+          const float4 pv = *reinterpret_cast<const float4*>(prow + si * 32);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.x, vr[si][0], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.y, vr[si][1], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv.z, vr[si][2], acc, 0, 0, 0);
@@ -1129,13 +1152,14 @@ __global__ void k_loop_init(LoopArgs a) {
 // One block.  Verify each draft against the argmax tokens, keep the longest accepted prefix plus one
 // bonus token, retire rows that produced EOS, compact the active list, decide whether the loop goes on.
 __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
-  __shared__ int s_maxfront, s_anyfin;
+  __shared__ int s_maxfront, s_anyfin, s_suspect, s_nn, s_maxf_new;
   __shared__ long long s_acc, s_prefix;
+  __shared__ int s_scan[256];
   DecState* st = a.st;
   const int Bc = st->n_active;
   if (Bc == 0) return;
   const int D1 = a.D + 1, RPS = step_rps(a.N, a.D);
-  if (threadIdx.x == 0) { s_maxfront = 0; s_anyfin = 0; s_acc = 0; s_prefix = 0; }
+  if (threadIdx.x == 0) { s_maxfront = 0; s_anyfin = 0; s_acc = 0; s_prefix = 0; s_suspect = 0; s_nn = 0; s_maxf_new = 0; }
   __syncthreads();
   for (int slot = threadIdx.x; slot < Bc; slot += blockDim.x) {
     const int b = a.act_idx[slot];
@@ -1152,18 +1176,17 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     }
     const int* pr = ps + 1 + best * a.D - 1;
     int* g = a.gen + (size_t)b * a.gen_ld;
-    bool fin = false;
+    bool fin = false, sawpad = false;
     for (int j = 0; j <= bacc; ++j) {
       const int t = (j == 0) ? ps[0] : pr[j];
       g[f + 1 + j] = t;
       fin |= (t == a.eos);
-      if (t == a.pad) a.haspad[b] = 1;             // a PAD inside the generated part (reference quirk 2)
+      sawpad |= (t == a.pad);                          // a PAD inside the generated part (reference quirk 2)
     }
+    if (sawpad) a.haspad[b] = 1;
     a.front[b] = f + bacc + 1;
-    a.rec[slot] = CopyRec{b, best, bacc, f};
-    // the reference tests the whole row for EOS (:149); earlier positions can only hold EOS if the
-    // model emitted it as a non-final accepted token, which the per-step test above already caught
-    a.rec[slot].b = fin ? -(b + 1) : b;          // negative marks "finished this step"
+    // the reference tests the whole row for EOS (:149); earlier positions cannot hold it (the row would have retired)
+    a.rec[slot] = CopyRec{fin ? -(b + 1) : b, best, bacc, f};      // negative b marks "finished this step"
     atomicMax(&s_maxfront, f);
     atomicAdd((unsigned long long*)&s_acc, (unsigned long long)bacc);
     atomicAdd((unsigned long long*)&s_prefix, (unsigned long long)f);
@@ -1172,9 +1195,30 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
   __syncthreads();
   const int width = s_maxfront + 1 + D1;          // columns of generated_tokens after this step (:97-102,:145)
   const int wcopy = width < a.max_len ? width : a.max_len;
-  // finished rows -> output (:158)
+  // finished rows -> output (:158); compaction of the running list by a block-wide ordered scan
+  int nn_before = 0;
+  for (int base = 0; base < Bc; base += blockDim.x) {
+    const int slot = base + threadIdx.x;
+    const int code = slot < Bc ? a.rec[slot].b : -1;
+    const int keep = (slot < Bc && code >= 0) ? 1 : 0;
+    s_scan[threadIdx.x] = keep;
+    __syncthreads();
+    for (int off = 1; off < blockDim.x; off <<= 1) {   // inclusive Hillis-Steele scan over <= 256 flags
+      const int v = (threadIdx.x >= off) ? s_scan[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (keep) {
+      a.act_idx[nn_before + s_scan[threadIdx.x] - 1] = code;
+      if (a.haspad[code]) s_suspect = 1;
+      atomicMax(&s_maxf_new, a.front[code]);
+    }
+    nn_before += s_scan[blockDim.x - 1];
+    __syncthreads();
+  }
   for (int slot = 0; slot < Bc; ++slot) {
-    const int code = a.rec[slot].b;
+    const int code = a.rec[slot].b;                 // uniform over the block
     if (code < 0) {
       const int b = -code - 1;
       const int* g = a.gen + (size_t)b * a.gen_ld;
@@ -1182,13 +1226,10 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     }
   }
   __syncthreads();
+  for (int slot = threadIdx.x; slot < Bc; slot += blockDim.x)
+    if (a.rec[slot].b < 0) a.rec[slot].b = -a.rec[slot].b - 1;
   if (threadIdx.x == 0) {
-    int nn = 0;
-    for (int slot = 0; slot < Bc; ++slot) {
-      const int code = a.rec[slot].b;
-      if (code >= 0) a.act_idx[nn++] = code;
-      else a.rec[slot].b = -code - 1;
-    }
+    const int nn = nn_before;
     st->n_copy = Bc;
     st->steps += 1;
     st->accepted += s_acc;
@@ -1199,26 +1240,18 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     st->width = width;
     if (s_anyfin && width > a.max_len) st->error = 1;
     int stop = (nn == 0 || width >= a.max_len) ? 1 : 0;
-    if (!stop) {
+    if (!stop && s_suspect) {
       // Reference quirk 2 (speculative_decoding.py:97,111-115): if some column up to the longest running row's
       // front is PAD in every running row, the reference under-sizes its padded tensor and the draft scatter
-      // raises.  Only possible when a running row holds a PAD token, so the scan below almost never runs.
-      bool suspect = false;
-      int maxf = 0;
-      for (int i = 0; i < nn; ++i) {
-        const int b = a.act_idx[i];
-        suspect |= (a.haspad[b] != 0);
-        maxf = max(maxf, a.front[b]);
-      }
-      if (suspect) {
-        for (int c = 0; c <= maxf && !stop; ++c) {
-          bool allpad = true;
-          for (int i = 0; i < nn && allpad; ++i) {
-            const int b = a.act_idx[i];
-            if (a.front[b] >= c && a.gen[(size_t)b * a.gen_ld + c] != a.pad) allpad = false;
-          }
-          if (allpad) { st->error = 2; stop = 1; }
+      // raises.  Only possible when a running row holds a PAD token, so this scan almost never runs.
+      const int maxf = s_maxf_new;
+      for (int c = 0; c <= maxf && !stop; ++c) {
+        bool allpad = true;
+        for (int i = 0; i < nn && allpad; ++i) {
+          const int b = a.act_idx[i];
+          if (a.front[b] >= c && a.gen[(size_t)b * a.gen_ld + c] != a.pad) allpad = false;
         }
+        if (allpad) { st->error = 2; stop = 1; }
       }
     }
     st->stop = stop;
