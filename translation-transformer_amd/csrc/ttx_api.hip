@@ -289,6 +289,7 @@ struct ttx_session {
   // profiling of the GEMM launches (bench.py roofline)
   bool profile = false;
   bool gemm_v1 = false, attn_v1 = false;
+  int ffn2_split = 8;              // split-K factor of the step's K >= 2048 GEMM (FFN2) on the 32x32 kernel
   int gemm3_max_n = 768;           // step GEMMs at most this wide use the 32x32 kernel (k_gemm3)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -343,6 +344,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   s->profile = pf && pf[0] == '1';
   s->gemm_v1 = getenv("TTX_GEMM_V1") != nullptr;
   if (const char* g3 = getenv("TTX_GEMM3_MAX_N")) s->gemm3_max_n = atoi(g3);
+  if (const char* f2 = getenv("TTX_FFN2_SPLIT")) s->ffn2_split = std::max(1, atoi(f2));
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
@@ -385,7 +387,7 @@ static bool use_gemm3(const ttx_session* s, bool step, int N, int K, int k_per_s
 
 static int choose_splits(const ttx_session* s, bool step, int N, int K) {
   if (!step) return 1;
-  if (N <= s->gemm3_max_n && !s->gemm_v1) return (K >= 2048 && K % 1024 == 0) ? 2 : 1;   // k_gemm3: K already split over 4 waves
+  if (N <= s->gemm3_max_n && !s->gemm_v1) return (K >= 2048 && K % (256 * s->ffn2_split) == 0) ? s->ffn2_split : 1;   // k_gemm3: K also split over the 4 waves
   int S = 1;                                                                                // k_gemm2: 64-wide tiles of a d-wide output
   while (S < 8 && K / (S * 2) >= 64 && (K % (S * 2 * 64)) == 0 && cdiv(N, 64) * S < 32) S *= 2;
   return S;
