@@ -64,8 +64,9 @@ def gather_predictions(local: torch.Tensor, n_items: int, dist=None, dst: int = 
     W = int(width.item())
     buf = torch.full((per, local.shape[1], W), pad_value, dtype=dt, device=local.device)
     buf[:local.shape[0], :, :local.shape[2]] = local.to(dt)
-    parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, parts, dst=dst)
+    # all_gather rather than gather: supported by every RCCL/NCCL/gloo build; the extra copies are a few MB once per run
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
     if rank != dst:
         return None
     out = []
