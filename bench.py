@@ -261,7 +261,7 @@ def main():
             pstats["model_calls"] = pg.model_calls_num
             pw = flops_and_bytes(cfg, pstats, pstats["src_tokens_padded"], len(timed))
             ach = pw["gemm_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-            line["roofline"] = {"kernel": "k_gemm2 / k_gemm_tn (fp32 v_mfma_f32_32x32x2_f32 GEMM, every launch of the run)",
+            line["roofline"] = {"kernel": "k_gemm3 / k_gemm2 (fp32 v_mfma_f32_32x32x2_f32 GEMMs, every launch of the run)",
                                 "bound": "mfma", "achieved": ach,
                                 "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
                                 "traffic": None, "launches": launches, "avg_launch_us": 1e3 * raw_ms / max(1, launches),
