@@ -156,6 +156,22 @@ int ttx_tree_step(ttx_session* s, const int64_t* d_cand, int n_cand, int width, 
                   const int32_t* d_parent, const int32_t* d_parent_draft, const int32_t* d_src_row,
                   const uint8_t* d_active, const int64_t* d_drafts, int N, int D, float* d_logits, void* stream);
 
+/* Beam-speculative bookkeeping kernels.
+ * ttx_nucleus_mask: mask_with_num_logits_according_nucleus (src/decoding/speculative_decoding.py:871-904): per row of
+ *   d_logits [rows,V] keep the best logit and further ones, best first, while the softmax mass ranked above is
+ *   < nucleus, never more than n_best (<= 32); everything else becomes `fill`.  d_out [rows,V].  V <= 1024.
+ * ttx_accepted_lengths: the nucleus mask (0.9975-style) fused with calculate_n_accepted_in_drafts (:847-869):
+ *   d_logits [R,D+1,V], d_drafts int64 [R,D] -> d_n_ok int32 [R] = leading draft tokens inside their position's kept set.
+ * ttx_ragged_topk: topk_in_each_group (:177-238): d_score [sum of group lengths], d_offsets int32 [G+1] exclusive prefix
+ *   sums, every group >= k entries; d_top fp32 [G,k] and d_idx int64 [G,k] (flat indices) best first; equal scores: lower
+ *   index first (torch leaves ties unspecified). */
+int ttx_nucleus_mask(ttx_session* s, const float* d_logits, int rows, int V, float nucleus, int n_best, float fill,
+                     float* d_out, void* stream);
+int ttx_accepted_lengths(ttx_session* s, const float* d_logits, const int64_t* d_drafts, int R, int D, int V, float nucleus,
+                         int n_best, int32_t* d_n_ok, void* stream);
+int ttx_ragged_topk(ttx_session* s, const float* d_score, const int32_t* d_offsets, int G, int max_group, int k,
+                    float* d_top, int64_t* d_idx, void* stream);
+
 /* Several batches in flight on one GPU (the scheduling SURVEY.md §8(f) #1 names; the reference's predict loop
  * is strictly one batch at a time, src/model/lightning_model.py:209-212).  Batch i is decoded on
  * sessions[i % n_sessions]; each session runs on its own internal stream that first waits for `stream`

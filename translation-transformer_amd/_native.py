@@ -73,6 +73,9 @@ SYMBOLS = {
     "ttx_greedy_speculative_generate_many": (C.c_int, [C.POINTER(_VP), _I, _I, C.POINTER(_VP), C.POINTER(C.c_int),
                                                       C.POINTER(C.c_int), C.POINTER(GenParams), C.POINTER(_VP),
                                                       C.POINTER(GenStats), _VP]),
+    "ttx_nucleus_mask": (C.c_int, [_VP, _VP, _I, _I, C.c_float, _I, C.c_float, _VP, _VP]),
+    "ttx_accepted_lengths": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _I, _VP, _VP]),
+    "ttx_ragged_topk": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "ttx_tree_begin": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "ttx_tree_step": (C.c_int, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "ttx_last_kernel_profile": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

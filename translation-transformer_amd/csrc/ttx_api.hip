@@ -1283,6 +1283,53 @@ extern "C" int ttx_tree_step(ttx_session* s, const int64_t* d_cand, int n_cand, 
   return TTX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Beam-speculative bookkeeping
+extern "C" int ttx_nucleus_mask(ttx_session* s, const float* d_logits, int rows, int V, float nucleus, int n_best, float fill,
+                                float* d_out, void* stream) {
+  if (!s || !d_logits || !d_out || rows < 0 || V <= 0) return fail(TTX_ERR_INVALID, "bad argument to ttx_nucleus_mask");
+  if (V > 64 * NUC_VPL) return fail(TTX_ERR_INVALID, "ttx_nucleus_mask: vocabulary larger than 1024");
+  if (n_best < 1 || n_best > NUC_MAX_KEEP) return fail(TTX_ERR_INVALID, "ttx_nucleus_mask: n_best must be in [1,32]");
+  if (rows == 0) return TTX_OK;
+  HIP_TRY(hipSetDevice(s->m->device));
+  NucleusArgs a{d_logits, rows, V, nucleus, n_best, fill, d_out, nullptr, 0, nullptr};
+  hipLaunchKernelGGL(k_nucleus, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+extern "C" int ttx_accepted_lengths(ttx_session* s, const float* d_logits, const int64_t* d_drafts, int R, int D, int V,
+                                    float nucleus, int n_best, int32_t* d_n_ok, void* stream) {
+  if (!s || !d_logits || !d_drafts || !d_n_ok || R < 0 || D <= 0 || V <= 0) return fail(TTX_ERR_INVALID, "bad argument to ttx_accepted_lengths");
+  if (V > 64 * NUC_VPL) return fail(TTX_ERR_INVALID, "ttx_accepted_lengths: vocabulary larger than 1024");
+  if (n_best < 1 || n_best > NUC_MAX_KEEP) return fail(TTX_ERR_INVALID, "ttx_accepted_lengths: n_best must be in [1,32]");
+  if (R == 0) return TTX_OK;
+  HIP_TRY(hipSetDevice(s->m->device));
+  NucleusArgs a{d_logits, R, V, nucleus, n_best, 0.f, nullptr, d_drafts, D, d_n_ok};
+  hipLaunchKernelGGL(k_nucleus, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+extern "C" int ttx_ragged_topk(ttx_session* s, const float* d_score, const int32_t* d_offsets, int G, int max_group, int k,
+                               float* d_top, int64_t* d_idx, void* stream) {
+  if (!s || !d_score || !d_offsets || !d_top || !d_idx || G < 0 || k < 1 || max_group < 1)
+    return fail(TTX_ERR_INVALID, "bad argument to ttx_ragged_topk");
+  if ((size_t)max_group * 4 > 150 * 1024) return fail(TTX_ERR_INVALID, "ttx_ragged_topk: group larger than the LDS image");
+  if (G == 0) return TTX_OK;
+  HIP_TRY(hipSetDevice(s->m->device));
+  const size_t lds = (size_t)max_group * 4;
+  static bool attr = false;
+  if (lds > 64 * 1024 && !attr) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ragged_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr = true;
+  }
+  RaggedTopkArgs a{d_score, d_offsets, k, d_top, d_idx};
+  hipLaunchKernelGGL(k_ragged_topk, dim3(G), dim3(256), lds, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
 extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms) {
   if (!s) return fail(TTX_ERR_INVALID, "null session");
   if (gemm_ms) *gemm_ms = s->prof_ms;

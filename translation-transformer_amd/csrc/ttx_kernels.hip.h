@@ -1336,6 +1336,148 @@ __global__ __launch_bounds__(256) void k_kvcopy(KvCopyArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Beam-speculative bookkeeping kernels.
+//
+// k_nucleus: mask_with_num_logits_according_nucleus (speculative_decoding.py:871-904) without the full sort: one wave
+// per distribution finds the n_best largest logits in descending order by repeated wavefront arg-max (each lane
+// keeps V/64 candidates in registers), accumulates their softmax mass in rank order in fp32 and keeps rank i while
+// the mass ranked above it is < nucleus (rank 0 always).  Either writes the masked row (kept logits, `fill`
+// elsewhere) or, fused with calculate_n_accepted_in_drafts (:847-869), only counts how many leading draft tokens
+// fall inside their position's kept set.
+constexpr int NUC_MAX_KEEP = 32;
+constexpr int NUC_VPL = 16;                 // logits per lane held in registers: V <= 1024
+
+struct NucleusArgs {
+  const float* logits; int rows; int V;    // [rows, V]
+  float nucleus; int n_best; float fill;
+  float* masked;                           // [rows, V] or null
+  // fused acceptance: rows are (r, j) pairs, j = 0..D (D+1 distributions per draft row); drafts [R, D]
+  const int64_t* drafts; int D; int* n_ok; // n_ok [R] (null: not fused)
+};
+
+__device__ __forceinline__ void nucleus_select(const float* __restrict__ p, int V, float nucleus, int n_best, int lane,
+                                               int (&kept_idx)[NUC_MAX_KEEP], float (&kept_val)[NUC_MAX_KEEP], int& n_kept) {
+  float v[NUC_VPL];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NUC_VPL; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < V ? p[c] : -INFINITY;
+    m = fmaxf(m, v[i]);
+  }
+  m = wave_max(m);
+  float z = 0.f;
+#pragma unroll
+  for (int i = 0; i < NUC_VPL; ++i) z += (lane + 64 * i < V) ? expf(v[i] - m) : 0.f;
+  z = wave_sum(z);
+  float above = 0.f;                        // softmax mass of the ranks already taken
+  n_kept = 0;
+  for (int rank = 0; rank < n_best && rank < V; ++rank) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < NUC_VPL; ++i)
+      if (v[i] > best || (v[i] == best && lane + 64 * i < bi && v[i] != -INFINITY)) { best = v[i]; bi = lane + 64 * i; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (bi == 0x7fffffff) break;            // nothing finite left
+    const bool keep = (rank == 0) || (above < nucleus);
+    if (!keep) break;                       // the mass above only grows: no later rank can be kept
+    kept_idx[n_kept] = bi;
+    kept_val[n_kept] = best;
+    ++n_kept;
+    above += expf(best - m) / z;
+#pragma unroll
+    for (int i = 0; i < NUC_VPL; ++i)
+      if (lane + 64 * i == bi) v[i] = -INFINITY;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_nucleus(NucleusArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (a.n_ok) {
+    // one wave per draft row: walk its D positions until the first draft token outside the kept set
+    if (row >= a.rows) return;
+    int ok = 0;
+    for (int j = 0; j < a.D; ++j) {
+      int ki[NUC_MAX_KEEP];
+      float kv[NUC_MAX_KEEP];
+      int nk;
+      nucleus_select(a.logits + ((size_t)row * (a.D + 1) + j) * a.V, a.V, a.nucleus, a.n_best, lane, ki, kv, nk);
+      const int tok = (int)a.drafts[(size_t)row * a.D + j];
+      bool hit = false;
+      for (int i = 0; i < nk; ++i) hit |= (ki[i] == tok);
+      if (!hit) break;
+      ++ok;
+    }
+    if (lane == 0) a.n_ok[row] = ok;
+    return;
+  }
+  if (row >= a.rows) return;
+  int ki[NUC_MAX_KEEP];
+  float kv[NUC_MAX_KEEP];
+  int nk;
+  nucleus_select(a.logits + (size_t)row * a.V, a.V, a.nucleus, a.n_best, lane, ki, kv, nk);
+  float* out = a.masked + (size_t)row * a.V;
+  for (int c = lane; c < a.V; c += 64) {
+    float val = a.fill;
+    for (int i = 0; i < nk; ++i)
+      if (ki[i] == c) val = kv[i];
+    out[c] = val;
+  }
+}
+
+// k_ragged_topk: topk_in_each_group (speculative_decoding.py:177-238): the k largest scores of every consecutive
+// group, best first, with their flat indices.  One workgroup per group, k rounds of block-wide arg-max
+// (ties: lower index first).
+struct RaggedTopkArgs {
+  const float* score; const int* offsets;  // offsets [G+1] (exclusive prefix sums of the group lengths)
+  int k; float* top; int64_t* idx;         // [G, k]
+};
+
+__global__ __launch_bounds__(256) void k_ragged_topk(RaggedTopkArgs a) {
+  extern __shared__ float vals[];          // the group's scores (taken ones become -inf)
+  __shared__ float s_best[4];
+  __shared__ int s_bi[4];
+  const int g = blockIdx.x;
+  const int lo = a.offsets[g], n = a.offsets[g + 1] - lo;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) vals[i] = a.score[lo + i];
+  __syncthreads();
+  for (int r = 0; r < a.k; ++r) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const float v = vals[i];
+      if (v > best || (v == best && i < bi && bi == 0x7fffffff)) { best = v; bi = i; }
+    }
+    // first maximum among equal values: per-thread scan ascends in i, so `bi` is already the lowest index it saw
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = best; s_bi[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (s_best[w] > best || (s_best[w] == best && s_bi[w] < bi)) { best = s_best[w]; bi = s_bi[w]; }
+      if (bi == 0x7fffffff) bi = (r < n) ? r : 0;      // group exhausted (all -inf): any remaining slot, as padding
+      a.top[(size_t)g * a.k + r] = best;
+      a.idx[(size_t)g * a.k + r] = lo + bi;
+      if (bi < n) vals[bi] = -INFINITY;
+      s_bi[0] = bi;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tree (beam) decoding with a per-candidate KV cache: SURVEY.md §2.3 K12-K14's decoder side.  A "candidate" is one
 // hypothesis row (n_best per source); its cache is rebuilt every step from its parent's cache plus the parent's
 // accepted step rows, then the same verify-step kernels run with candidate = running row.

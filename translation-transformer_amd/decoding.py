@@ -360,11 +360,19 @@ class _BeamSearchSpeculativeHost:
                 look = look | look.roll(-1, dims=1)
                 logits[running] = out[look].reshape(-1, dl + 1, V)
 
-            probs = _nucleus(logits, 0.9975, K, float("-inf")).softmax(-1)
-            alive = probs[:, :-1, :].gather(2, row_d.unsqueeze(-1)).squeeze(-1) != 0.0
-            n_ok = alive.long().cumprod(dim=1).sum(dim=1)
+            native = isinstance(m, NativeTransformer) and os.environ.get("TTX_BEAM_NATIVE_BOOKKEEPING", "1") != "0"
+            if native:                                                          # K11 fused with the acceptance count
+                n_ok = m.accepted_lengths(logits, row_d, 0.9975, K)
+            else:
+                probs = _nucleus(logits, 0.9975, K, float("-inf")).softmax(-1)
+                alive = probs[:, :-1, :].gather(2, row_d.unsqueeze(-1)).squeeze(-1) != 0.0
+                n_ok = alive.long().cumprod(dim=1).sum(dim=1)
             if smart:
-                best_n, best_row = _ragged_topk(n_ok, per_cand, 1, -1)
+                if native:
+                    best_n, best_row = m.ragged_topk(n_ok.float(), per_cand, 1)
+                    best_n = best_n.long()
+                else:
+                    best_n, best_row = _ragged_topk(n_ok, per_cand, 1, -1)
                 best_n = best_n.reshape(-1)
             else:
                 best_n, which = n_ok.reshape(n_cand, Nn).topk(1, dim=-1)
@@ -374,7 +382,8 @@ class _BeamSearchSpeculativeHost:
             cl = logits[best_row]
 
             pos = torch.arange(dl + 1, device=dev)
-            tree = _nucleus(cl, 20.0, K, 0.0) * (pos.unsqueeze(0) <= best_n.unsqueeze(1)).unsqueeze(-1)
+            topn = m.nucleus_mask(cl, 20.0, K, 0.0) if native else _nucleus(cl, 20.0, K, 0.0)
+            tree = topn * (pos.unsqueeze(0) <= best_n.unsqueeze(1)).unsqueeze(-1)
             short = torch.nonzero(best_n != dl).reshape(-1)
             chosen[short, best_n[short]] = BOS
             tree[:, :-1, :].scatter_(2, chosen.unsqueeze(-1), 0.0)
@@ -397,7 +406,11 @@ class _BeamSearchSpeculativeHost:
             mark = lpz.clone()
             mark[(cand[lc] == EOS).any(dim=1)] = -1
 
-            top_s, top_i = _ragged_topk(score, per_src, K, float("-inf"))
+            if native:
+                assert int(per_src.min()) >= K
+                top_s, top_i = m.ragged_topk(score, per_src, K)
+            else:
+                top_s, top_i = _ragged_topk(score, per_src, K, float("-inf"))
             prev_parent = lc[top_i]                                             # candidate of this step each survivor extends
             prev_pdraft = row_slot[best_row][prev_parent]                       # ... and the draft slot it kept tokens from
             cand = roots[top_i]

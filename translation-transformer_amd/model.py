@@ -151,6 +151,40 @@ class NativeTransformer:
 
     forward = __call__
 
+    # -- beam-speculative bookkeeping kernels --------------------------------------------------
+    def nucleus_mask(self, logits: torch.Tensor, nucleus: float, max_kept: int, fill: float) -> torch.Tensor:
+        """mask_with_num_logits_according_nucleus (speculative_decoding.py:871-904) on the device."""
+        shape = logits.shape
+        x = logits.to(self.device, torch.float32).contiguous().reshape(-1, shape[-1])
+        out = torch.empty_like(x)
+        N.check(self._lib.ttx_nucleus_mask(self._session, x.data_ptr(), x.shape[0], x.shape[1], float(nucleus), int(max_kept),
+                                           float(fill), out.data_ptr(), self._stream()))
+        return out.reshape(shape)
+
+    def accepted_lengths(self, logits: torch.Tensor, drafts: torch.Tensor, nucleus: float, max_kept: int) -> torch.Tensor:
+        """Leading draft tokens that survive the nucleus mask of their position (speculative_decoding.py:539-548, :847-869).
+        logits [R,D+1,V], drafts Long[R,D] -> Long[R]."""
+        R, D1, V = logits.shape
+        x = logits.to(self.device, torch.float32).contiguous()
+        d = drafts.to(self.device, torch.int64).contiguous()
+        out = torch.empty(R, dtype=torch.int32, device=self.device)
+        N.check(self._lib.ttx_accepted_lengths(self._session, x.data_ptr(), d.data_ptr(), R, D1 - 1, V, float(nucleus),
+                                               int(max_kept), out.data_ptr(), self._stream()))
+        return out.long()
+
+    def ragged_topk(self, score: torch.Tensor, counts: torch.Tensor, k: int):
+        """topk_in_each_group (speculative_decoding.py:177-238): (values [G,k], flat indices [G*k])."""
+        sc = score.to(self.device, torch.float32).contiguous().reshape(-1)
+        counts = counts.to(self.device)
+        offs = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=self.device)
+        offs[1:] = counts.cumsum(0)
+        G = counts.numel()
+        top = torch.empty((G, k), dtype=torch.float32, device=self.device)
+        idx = torch.empty((G, k), dtype=torch.int64, device=self.device)
+        N.check(self._lib.ttx_ragged_topk(self._session, sc.data_ptr(), offs.data_ptr(), G, int(counts.max()), int(k),
+                                          top.data_ptr(), idx.data_ptr(), self._stream()))
+        return top, idx.reshape(-1)
+
     def make_drafts(self, src: torch.Tensor, draft_len: int, n_drafts: int, min_draft_len: int, max_draft_len: int,
                     eos_token_idx: int, pad_token_idx: int, replace_token_idx: int) -> torch.Tensor:
         """src/utils/drafting.py:5-67 on the device."""
