@@ -111,7 +111,7 @@ typedef struct ttx_gen_params {
   int32_t draft_len;       /* greedy-speculative: D (clamped to [1,max_len] as speculative_decoding.py:64-73) */
   int32_t n_drafts;        /* N */
   int32_t pad_token, bos_token, eos_token, replace_token;
-  int32_t want_logits;     /* debug/parity: also keep pre-argmax logits of the verify positions */
+  int32_t want_logits;     /* parity tests: k > 0 records verify step k (1-based) for ttx_debug_step_snapshot */
 } ttx_gen_params;
 
 typedef struct ttx_gen_stats {
@@ -181,6 +181,14 @@ int ttx_greedy_speculative_generate_many(ttx_session** sessions, int n_sessions,
                                          const int64_t* const* d_src, const int* B, const int* Ls,
                                          const ttx_gen_params* p, int64_t* const* d_out, ttx_gen_stats* stats,
                                          void* stream);
+
+/* Parity instrumentation for the KV-cached verify step: the step selected by ttx_gen_params.want_logits (1-based step
+ * number) of the most recent generate call on `s` — its pre-argmax logits and the loop state they were computed from.
+ * HOST destinations: h_logits [n_active*rps, V], h_act int32 [n_active] (running rows in slot order), h_front int32 [B],
+ * h_gen int32 [B, gen_ld]; info[0..5] = n_active, rps (= 1 + N*D rows per sequence), B, gen_ld, V, step.  Any of the
+ * four array pointers may be null (e.g. a first call to learn the sizes). */
+int ttx_debug_step_snapshot(ttx_session* s, int32_t* info, float* h_logits, int32_t* h_act, int32_t* h_front,
+                            int32_t* h_gen);
 
 /* Timing of the dominant kernel for bench.py's roofline: summed HIP-event time (events recorded on the
  * launch stream around every k_gemm_tn launch) and launch count of the most recent generate call on this

@@ -166,3 +166,33 @@ def test_full_size_beam_speculative_matches_oracle(tta, full_pair):
         out = g.generate(sel.cuda()).cpu().numpy()
         for b in range(len(rows)):
             assert upto_eos(out[b, 0]) == upto_eos(exp[b, 0]), (smart, b)
+
+
+def test_kv_cached_step_logits_match_full_prefix_oracle(tta, full_pair):
+    """Pre-argmax logits of a KV-cached verify step (step 4 and step 9 of a running batch: cached prefixes of different
+    lengths, some rows already retired) against the oracle's full-prefix decode_tgt of the same token rows."""
+    from oracle.drafting import make_drafts
+    native, oracle = full_pair
+    src, _, c, V = fixture_tokens()
+    N_, D_ = 3, 10
+    mask = src == PAD
+    memory = oracle.encode_src(src, mask)
+    drafts = make_drafts(src[:, 1:], D_, N_, 1, 200, EOS, PAD, c).numpy()
+    worst = 0.0
+    for step in (1, 4, 9):
+        g = tta.TranslationInferenceGreedySpeculative(native, 200, D_, N_, PAD, BOS, EOS, c)
+        g.record_step = step
+        g.generate(src.cuda())
+        snap = g.step_snapshot()
+        assert snap["step"] == step and snap["logits"].shape[1] == 1 + N_ * D_
+        for slot, b in enumerate(snap["rows"].tolist()):
+            f = int(snap["front"][b])
+            prefix = snap["gen"][b, :f + 1].astype(np.int64)
+            for n in range(N_):
+                row = torch.from_numpy(np.concatenate([prefix, drafts[b, n]]))[None]
+                ref = oracle.decode_tgt(row, memory[b:b + 1], mask[b:b + 1])[0, f:f + D_ + 1]         # positions f .. f+D
+                got = np.concatenate([snap["logits"][slot, :1], snap["logits"][slot, 1 + n * D_:1 + (n + 1) * D_]])
+                worst = max(worst, float(np.abs(got - ref.numpy()).max()))
+                assert np.array_equal(got.argmax(-1), ref.numpy().argmax(-1))
+    print("KV-cached verify-step logits vs full-prefix oracle: max abs diff", worst)
+    assert worst < 1e-3

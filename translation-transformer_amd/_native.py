@@ -78,6 +78,7 @@ SYMBOLS = {
     "ttx_ragged_topk": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "ttx_tree_begin": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "ttx_tree_step": (C.c_int, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "ttx_debug_step_snapshot": (C.c_int, [_VP, C.POINTER(C.c_int32), _VP, _VP, _VP, _VP]),
     "ttx_last_kernel_profile": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 

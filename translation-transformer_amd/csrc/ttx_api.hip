@@ -268,6 +268,9 @@ struct ttx_session {
   Buf tok_tgt, mem_pad_tmp;
   // loop
   Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf, dbg_self, dbg_cross, haspad;
+  // snapshot of one verify step for the logits parity test (ttx_gen_params.want_logits)
+  Buf snap_logits, snap_act, snap_front, snap_gen, snap_state;
+  int snap_B = 0, snap_rps = 0, snap_gen_ld = 0, snap_step = 0;
   // tree (beam) decoding
   Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of, t_len, t_parent, t_parent_draft, t_active;
   struct { int B = 0, Ls = 0, max_cand = 0, max_len = 0, N = 0, D = 0, Lc = 0, gen_ld = 0, cur = 0, prev_N = 1, prev_D = 0, steps = 0; } tree;
@@ -303,7 +306,8 @@ struct ttx_session {
   ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
                                  &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &tk[0], &tk[1], &tv[0], &tv[1],
-                                 &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active, &dbg_gemm}) all.push_back(b); }
+                                 &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active, &dbg_gemm,
+                                 &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state}) all.push_back(b); }
 };
 
 static thread_local uint64_t* g_alloc_gen = nullptr;   // alloc_generation of the session being sized
@@ -837,6 +841,7 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   const int N = greedy ? 1 : p->n_drafts, D = greedy ? 0 : p->draft_len, D1 = D + 1;
   const int max_len = p->max_len;
   j.s = s; j.st = st; j.greedy = greedy; j.d_out = d_out; j.stats = stats; j.launched = 0;
+  s->snap_step = 0;
   GenCtx& g = j.g;
   g = GenCtx{};
   g.k.B = B; g.k.Ls = Ls; g.k.N = N; g.k.D = D; g.k.max_len = max_len; g.k.p = *p;
@@ -923,9 +928,26 @@ static int gen_launch_step(GenJob& j, int width_bound) {
   const StepCtx& k = j.g.k;
   // prefix keys this step can see: < width_bound; bucket the LDS images of the self-attention in steps of 64 keys
   int kcap = std::min(k.max_len, ((std::max(width_bound, 1) + 63) / 64) * 64);
-  const bool use_graph = s->use_graphs && !s->profile;
+  const bool snapshot = (k.p.want_logits > 0 && k.p.want_logits == j.launched + 1);
+  const bool use_graph = s->use_graphs && !s->profile && !snapshot;
   if (!use_graph) {
     TTX_TRY(run_step(s, j.st, k, kcap));
+    if (snapshot) {
+      // keep this step's pre-argmax logits and the loop state they belong to (before accept changes it)
+      const ttx_config& c = s->m->cfg;
+      const size_t Mmax = (size_t)k.B * step_rps(k.N, k.D);
+      TTX_TRY(ensure(s->snap_logits, Mmax * c.vocab_size * 4, j.st));
+      TTX_TRY(ensure(s->snap_act, (size_t)k.B * 4, j.st));
+      TTX_TRY(ensure(s->snap_front, (size_t)k.B * 4, j.st));
+      TTX_TRY(ensure(s->snap_gen, (size_t)k.B * k.gen_ld * 4, j.st));
+      TTX_TRY(ensure(s->snap_state, sizeof(DecState), j.st));
+      HIP_TRY(hipMemcpyAsync(s->snap_logits.p, s->logits.p, Mmax * c.vocab_size * 4, hipMemcpyDeviceToDevice, j.st));
+      HIP_TRY(hipMemcpyAsync(s->snap_act.p, s->act_idx.p, (size_t)k.B * 4, hipMemcpyDeviceToDevice, j.st));
+      HIP_TRY(hipMemcpyAsync(s->snap_front.p, s->front.p, (size_t)k.B * 4, hipMemcpyDeviceToDevice, j.st));
+      HIP_TRY(hipMemcpyAsync(s->snap_gen.p, s->gen.p, (size_t)k.B * k.gen_ld * 4, hipMemcpyDeviceToDevice, j.st));
+      HIP_TRY(hipMemcpyAsync(s->snap_state.p, s->state.p, sizeof(DecState), hipMemcpyDeviceToDevice, j.st));
+      s->snap_B = k.B; s->snap_rps = step_rps(k.N, k.D); s->snap_gen_ld = k.gen_ld; s->snap_step = j.launched + 1;
+    }
     TTX_TRY(launch_accept_and_commit(s, j.st, j.g, j.greedy));
     ++j.launched;
     return TTX_OK;
@@ -1327,6 +1349,27 @@ extern "C" int ttx_ragged_topk(ttx_session* s, const float* d_score, const int32
   RaggedTopkArgs a{d_score, d_offsets, k, d_top, d_idx};
   hipLaunchKernelGGL(k_ragged_topk, dim3(G), dim3(256), lds, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+// Parity instrumentation: the verify step selected by ttx_gen_params.want_logits (1-based step number) of the most
+// recent generate call on this session: its pre-argmax logits and the loop state they were computed from.
+// All destinations are HOST pointers; sizes: logits [n_active*rps, V], act [n_active], front [B], gen [B, gen_ld].
+// info[0..5] = n_active, rps (rows per sequence = 1 + N*D), B, gen_ld, V, step.  Pass nulls to query info only.
+extern "C" int ttx_debug_step_snapshot(ttx_session* s, int32_t* info, float* h_logits, int32_t* h_act, int32_t* h_front,
+                                       int32_t* h_gen) {
+  if (!s || !info) return fail(TTX_ERR_INVALID, "null argument to ttx_debug_step_snapshot");
+  if (s->snap_step == 0) return fail(TTX_ERR_INVALID, "no verify step was recorded (set ttx_gen_params.want_logits)");
+  HIP_TRY(hipSetDevice(s->m->device));
+  HIP_TRY(hipDeviceSynchronize());
+  DecState st;
+  HIP_TRY(hipMemcpy(&st, s->snap_state.p, sizeof(DecState), hipMemcpyDeviceToHost));
+  const int V = s->m->cfg.vocab_size;
+  info[0] = st.n_active; info[1] = s->snap_rps; info[2] = s->snap_B; info[3] = s->snap_gen_ld; info[4] = V; info[5] = s->snap_step;
+  if (h_logits) HIP_TRY(hipMemcpy(h_logits, s->snap_logits.p, (size_t)st.n_active * s->snap_rps * V * 4, hipMemcpyDeviceToHost));
+  if (h_act) HIP_TRY(hipMemcpy(h_act, s->snap_act.p, (size_t)st.n_active * 4, hipMemcpyDeviceToHost));
+  if (h_front) HIP_TRY(hipMemcpy(h_front, s->snap_front.p, (size_t)s->snap_B * 4, hipMemcpyDeviceToHost));
+  if (h_gen) HIP_TRY(hipMemcpy(h_gen, s->snap_gen.p, (size_t)s->snap_B * s->snap_gen_ld * 4, hipMemcpyDeviceToHost));
   return TTX_OK;
 }
 

@@ -37,6 +37,23 @@ class TranslationInferenceGreedySpeculative:
                             "kv_prefix_positions": 0, "src_positions": 0, "encode_ms": 0.0, "decode_ms": 0.0,
                             "src_tokens_padded": 0, "batches": 0}
         self.last_stats: N.GenStats | None = None
+        self.record_step = 0           # parity tests: k > 0 keeps the logits of verify step k (see step_snapshot)
+
+    def step_snapshot(self) -> dict:
+        """The verify step recorded through ``record_step`` during the last ``generate``: numpy arrays
+        logits [n_active, rps, V], rows [n_active] (batch row of every slot), front [B], gen [B, gen_ld]."""
+        import numpy as np
+        m = self.model
+        info = (C.c_int32 * 6)()
+        N.check(m._lib.ttx_debug_step_snapshot(m.session, info, None, None, None, None))
+        n_act, rps, B, gen_ld, V, step = list(info)
+        logits = np.empty((n_act, rps, V), dtype=np.float32)
+        act = np.empty(n_act, dtype=np.int32)
+        front = np.empty(B, dtype=np.int32)
+        gen = np.empty((B, gen_ld), dtype=np.int32)
+        N.check(m._lib.ttx_debug_step_snapshot(m.session, info, logits.ctypes.data, act.ctypes.data, front.ctypes.data,
+                                               gen.ctypes.data))
+        return {"logits": logits, "rows": act, "front": front, "gen": gen, "step": step}
 
     def __str__(self):
         return (f"Greedy speculative decoding (draft_len={self.draft_len}, n_drafts={self.n_drafts}, "
@@ -48,7 +65,7 @@ class TranslationInferenceGreedySpeculative:
         B, Ls = src.shape
         out = torch.empty((B, 1, self.max_len), dtype=torch.int64, device=m.device)
         p = N.GenParams(self.max_len, self.draft_len, self.n_drafts, self.pad_token, self.bos_token, self.eos_token,
-                        self.replace_token, 0)
+                        self.replace_token, int(self.record_step))
         st = N.GenStats()
         N.check(m._lib.ttx_greedy_speculative_generate(m.session, src.data_ptr(), B, Ls, C.byref(p), out.data_ptr(),
                                                        C.byref(st), m._stream()))
