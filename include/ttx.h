@@ -182,6 +182,21 @@ int ttx_greedy_speculative_generate_many(ttx_session** sessions, int n_sessions,
                                          const ttx_gen_params* p, int64_t* const* d_out, ttx_gen_stats* stats,
                                          void* stream);
 
+/* Host-side string work either side of the hot path (no GPU) ------------------------------------
+ * ChemSMILESTokenizer (src/data_handling/tokenizer_smiles.py:8-39), the pad_sequence collate
+ * (src/data_handling/seq2seq_wrappers.py:121-127) and GenericTokenizer.decode (tokenizer_base.py:80-91).
+ * ttx_tokenizer_create takes the vocabulary as parallel arrays (token string, id), i.e. the reference's vocab.json
+ * (decoder_dict); service ids are the reference's fixed PAD=0, BOS=1, EOS=2, UNK=3.
+ * encode: number of ids the line needs (BOS/EOS included), writing min(that, cap) of them;
+ * encode_batch: int64 [B, cap_cols] padded with PAD, returns the padded width (or -needed if cap_cols is too small);
+ * decode: skips service tokens, stops at the first EOS, returns the string length, writes a NUL-terminated string. */
+typedef struct ttx_tokenizer ttx_tokenizer;
+int  ttx_tokenizer_create(const char* const* tokens, const int32_t* ids, int n, ttx_tokenizer** out);
+void ttx_tokenizer_destroy(ttx_tokenizer* t);
+int  ttx_tokenizer_encode(const ttx_tokenizer* t, const char* line, int32_t* out, int cap);
+int  ttx_tokenizer_encode_batch(const ttx_tokenizer* t, const char* const* lines, int B, int64_t* out, int cap_cols);
+int  ttx_tokenizer_decode(const ttx_tokenizer* t, const int64_t* ids, int n, char* out, int cap);
+
 /* Parity instrumentation for the KV-cached verify step: the step selected by ttx_gen_params.want_logits (1-based step
  * number) of the most recent generate call on `s` — its pre-argmax logits and the loop state they were computed from.
  * HOST destinations: h_logits [n_active*rps, V], h_act int32 [n_active] (running rows in slot order), h_front int32 [B],

@@ -405,7 +405,38 @@ def section_helpers():
     print("helpers ok")
 
 
-SECTIONS = dict(tokens=section_tokens, tiny=section_tiny, model=section_model, fullsize=section_fullsize,
+def section_tokenizer():
+    """G5 extended: the reference tokenizer (regex split, encode with BOS/EOS/UNK, decode to first EOS) on the fixture
+    lines and on synthetic SMILES-like strings that exercise every alternative of its regex (tokenizer_smiles.py:8)."""
+    from data_handling.tokenizer_smiles import SimpleSmilesTokenizer
+    src, tgt = load_fixture_lines()
+    tkz = ChemSMILESTokenizer()
+    tkz.train_tokenizer(src + tgt)
+    rng = np.random.default_rng(2024)
+    atoms = ["C", "N", "O", "S", "P", "F", "I", "B", "Br", "Cl", "b", "c", "n", "o", "s", "p", "[Na+]", "[O-]", "[N+]", "[nH]",
+             "[C@@H]", "[13CH3]", "(", ")", ".", "=", "#", "-", "+", "\\", "/", ":", "~", "@", "?", ">", "*", "$", "%10", "%99",
+             "1", "2", "9", "0"]
+    junk = ["X", "x", "Z", "[", "]", "%", "%1", "[]", "[ab", " ", "r", "l", "é", "H", "Si", "Se"]
+    lines = list(src) + list(tgt)
+    for _ in range(400):
+        n = int(rng.integers(1, 40))
+        parts = []
+        for _ in range(n):
+            pool = junk if rng.random() < 0.12 else atoms
+            parts.append(pool[int(rng.integers(0, len(pool)))])
+        lines.append("".join(parts))
+    lines += ["", "[", "]", "[[C]]", "Brr", "ClCl", "BrCl", "%123", "%1a", "C%12C", "\\\\", "C1=CC=CC=C1", "[Na+].[Cl-]"]
+    pieces = [SimpleSmilesTokenizer.split_into_tokens(l) for l in lines]
+    ids = [tkz.encode(l) for l in lines]
+    dec = [tkz.decode(np.array(i)) for i in ids]
+    dec_raw = [tkz.decode(np.array(i), skip_service_tokens=False) for i in ids]
+    (HERE / "tokenizer_cases.json").write_text(json.dumps(
+        {"vocab": {str(k): v for k, v in tkz.decoder_dict.items()}, "lines": lines, "pieces": pieces, "ids": ids,
+         "decoded": dec, "decoded_with_service": dec_raw}, ensure_ascii=False))
+    print("tokenizer:", len(lines), "lines,", sum(len(p) for p in pieces), "tokens")
+
+
+SECTIONS = dict(tokenizer=section_tokenizer, tokens=section_tokens, tiny=section_tiny, model=section_model, fullsize=section_fullsize,
                 drafts=section_drafts, greedy=section_greedy, beam=section_beam,
                 spec_greedy=section_spec_greedy, spec_beam=section_spec_beam, helpers=section_helpers)
 

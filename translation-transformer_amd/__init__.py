@@ -7,3 +7,4 @@ from .decoding import (TranslationInferenceGreedySpeculative, TranslationInferen
                        TranslationInferenceBeamSearch, TranslationInferenceBeamSearchSpeculative)
 from .lightning_model import VanillaEncoderDecoderTransformerLightning, run_predict  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
+from .tokenizer import NativeSmilesTokenizer  # noqa: F401,E402

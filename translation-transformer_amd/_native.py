@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = PKG_DIR / "libttx_hip.so"
-SOURCES = [CSRC / "ttx_api.hip", CSRC / "ttx_kernels.hip.h", INCLUDE / "ttx.h"]
+SOURCES = [CSRC / "ttx_api.hip", CSRC / "ttx_kernels.hip.h", CSRC / "ttx_tokenizer.h", INCLUDE / "ttx.h"]
 
 TTX_OK, TTX_ERR_INVALID, TTX_ERR_HIP, TTX_ERR_NO_DEVICE, TTX_ERR_REFERENCE, TTX_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -78,6 +78,11 @@ SYMBOLS = {
     "ttx_ragged_topk": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "ttx_tree_begin": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "ttx_tree_step": (C.c_int, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "ttx_tokenizer_create": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), _I, C.POINTER(_VP)]),
+    "ttx_tokenizer_destroy": (None, [_VP]),
+    "ttx_tokenizer_encode": (C.c_int, [_VP, C.c_char_p, _VP, _I]),
+    "ttx_tokenizer_encode_batch": (C.c_int, [_VP, C.POINTER(C.c_char_p), _I, _VP, _I]),
+    "ttx_tokenizer_decode": (C.c_int, [_VP, _VP, _I, _VP, _I]),
     "ttx_debug_step_snapshot": (C.c_int, [_VP, C.POINTER(C.c_int32), _VP, _VP, _VP, _VP]),
     "ttx_last_kernel_profile": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

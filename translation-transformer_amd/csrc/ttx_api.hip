@@ -2,6 +2,7 @@
 // No CPU fallback exists anywhere in this file: without a gfx950 device every entry point fails.
 #include "ttx.h"
 #include "ttx_kernels.hip.h"
+#include "ttx_tokenizer.h"
 
 #include <chrono>
 #include <cmath>
@@ -1371,6 +1372,79 @@ extern "C" int ttx_debug_step_snapshot(ttx_session* s, int32_t* info, float* h_l
   if (h_front) HIP_TRY(hipMemcpy(h_front, s->snap_front.p, (size_t)s->snap_B * 4, hipMemcpyDeviceToHost));
   if (h_gen) HIP_TRY(hipMemcpy(h_gen, s->snap_gen.p, (size_t)s->snap_B * s->snap_gen_ld * 4, hipMemcpyDeviceToHost));
   return TTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-side tokenizer / collate / detokenizer (no GPU)
+extern "C" int ttx_tokenizer_create(const char* const* tokens, const int32_t* ids, int n, ttx_tokenizer** out) {
+  if (!tokens || !ids || n <= 0 || !out) return fail(TTX_ERR_INVALID, "bad argument to ttx_tokenizer_create");
+  ttx_tokenizer* t = new ttx_tokenizer();
+  int32_t max_id = -1;
+  for (int i = 0; i < n; ++i) max_id = std::max(max_id, ids[i]);
+  t->dec.assign((size_t)max_id + 1, std::string());
+  for (int i = 0; i < n; ++i) {
+    if (!tokens[i] || ids[i] < 0) { delete t; return fail(TTX_ERR_INVALID, "vocabulary entry with a null token or negative id"); }
+    t->enc[tokens[i]] = ids[i];
+    t->dec[ids[i]] = tokens[i];
+  }
+  *out = t;
+  return TTX_OK;
+}
+
+extern "C" void ttx_tokenizer_destroy(ttx_tokenizer* t) { delete t; }
+
+// ChemSMILESTokenizer.encode: returns the number of ids the line needs (BOS and EOS included); writes min(that, cap).
+extern "C" int ttx_tokenizer_encode(const ttx_tokenizer* t, const char* line, int32_t* out, int cap) {
+  if (!t || !line) return fail(TTX_ERR_INVALID, "null argument to ttx_tokenizer_encode");
+  int n = 0;
+  auto put = [&](int32_t id) { if (out && n < cap) out[n] = id; ++n; };
+  put(t->bos);
+  std::string piece;
+  ttxtok::split(line, std::strlen(line), [&](const char* p, size_t len) {
+    piece.assign(p, len);
+    auto it = t->enc.find(piece);
+    put(it == t->enc.end() ? t->unk : it->second);
+  });
+  put(t->eos);
+  return n;
+}
+
+// Tokenize B lines and pad them to the longest (the DataModule's collate: seq2seq_wrappers.py:121-127).  `out` is int64
+// [B, cap_cols] row-major (HOST); returns the padded width (<= cap_cols) or, if some line needs more columns, minus the
+// width required (nothing usable is written then).
+extern "C" int ttx_tokenizer_encode_batch(const ttx_tokenizer* t, const char* const* lines, int B, int64_t* out, int cap_cols) {
+  if (!t || !lines || B <= 0 || !out || cap_cols <= 0) return fail(TTX_ERR_INVALID, "bad argument to ttx_tokenizer_encode_batch");
+  std::vector<int32_t> row((size_t)cap_cols);
+  int width = 0;
+  for (int b = 0; b < B; ++b) {
+    const int n = ttx_tokenizer_encode(t, lines[b], row.data(), cap_cols);
+    if (n < 0) return n;
+    width = std::max(width, n);
+    if (n <= cap_cols) {
+      for (int i = 0; i < n; ++i) out[(size_t)b * cap_cols + i] = row[i];
+      for (int i = n; i < cap_cols; ++i) out[(size_t)b * cap_cols + i] = t->pad;
+    }
+  }
+  return width <= cap_cols ? width : -width;
+}
+
+// GenericTokenizer.decode with skip_service_tokens=True: returns the string length (NUL excluded) the ids need; writes at
+// most cap-1 characters and a terminating NUL.  Ids outside the vocabulary fail (the reference raises KeyError).
+extern "C" int ttx_tokenizer_decode(const ttx_tokenizer* t, const int64_t* ids, int n, char* out, int cap) {
+  if (!t || (!ids && n > 0)) return fail(TTX_ERR_INVALID, "null argument to ttx_tokenizer_decode");
+  size_t len = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t id = ids[i];
+    if (id != t->bos && id != t->eos && id != t->pad) {
+      if (id < 0 || (size_t)id >= t->dec.size() || (t->dec[id].empty() && t->enc.find("") == t->enc.end()))
+        return fail(TTX_ERR_REFERENCE, "token id outside the vocabulary (KeyError in the reference)");
+      const std::string& tok = t->dec[id];
+      for (char ch : tok) { if (out && (int)len + 1 < cap) out[len] = ch; ++len; }
+    }
+    if (id == t->eos) break;
+  }
+  if (out && cap > 0) out[std::min(len, (size_t)cap - 1)] = '\0';
+  return (int)len;
 }
 
 extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms) {
