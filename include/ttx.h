@@ -171,6 +171,19 @@ int ttx_accepted_lengths(ttx_session* s, const float* d_logits, const int64_t* d
                          int n_best, int32_t* d_n_ok, void* stream);
 int ttx_ragged_topk(ttx_session* s, const float* d_score, const int32_t* d_offsets, int G, int max_group, int k,
                     float* d_top, int64_t* d_idx, void* stream);
+/* ttx_beam_expand: one iteration's candidate expansion — `sample` (speculative_decoding.py:294-400: every single-token
+ *   deviation along the accepted prefix of each candidate's chosen draft, scored by cumulative log-probability), the
+ *   per-source top-n_best (:573-576) and the assembly of the new candidate rows (:393-395), fused in two kernels.
+ *   d_cl [n_cand,dl+1,V] logits along the chosen drafts; d_chosen int64 [n_cand,dl]; d_best_n int64 [n_cand]; d_logp [n_cand];
+ *   d_cand int64 [n_cand,width] left-aligned rows with >= dl+1 trailing PAD; d_len int32 real tokens per row;
+ *   d_chosen_slot int32 [n_cand]; d_finished uint8 [n_cand]; n_cand = B*beam (beam = 1 on the first iteration, else K).
+ *   Outputs for the B*K survivors, best first per source: rows, log-probs, parent candidate, the parent's draft slot, and
+ *   the accepted-token mark (-1 for rows that were already finished).  h_summary is a HOST int32[5]. */
+int ttx_beam_expand(ttx_session* s, const float* d_cl, const int64_t* d_chosen, const int64_t* d_best_n, const float* d_logp,
+                    const int64_t* d_cand, int width, const int32_t* d_len, const int32_t* d_chosen_slot,
+                    const uint8_t* d_finished, int B, int beam, int dl, int V, int K, int pad, int bos, int eos,
+                    int64_t* d_new_cand, float* d_new_logp, int32_t* d_parent, int32_t* d_parent_draft, int32_t* d_mark,
+                    int32_t* h_summary, void* stream);
 
 /* Several batches in flight on one GPU (the scheduling SURVEY.md §8(f) #1 names; the reference's predict loop
  * is strictly one batch at a time, src/model/lightning_model.py:209-212).  Batch i is decoded on

@@ -76,6 +76,8 @@ SYMBOLS = {
     "ttx_nucleus_mask": (C.c_int, [_VP, _VP, _I, _I, C.c_float, _I, C.c_float, _VP, _VP]),
     "ttx_accepted_lengths": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _I, _VP, _VP]),
     "ttx_ragged_topk": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "ttx_beam_expand": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP,
+                                  _VP, _VP, C.POINTER(C.c_int32), _VP]),
     "ttx_tree_begin": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "ttx_tree_step": (C.c_int, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "ttx_tokenizer_create": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), _I, C.POINTER(_VP)]),

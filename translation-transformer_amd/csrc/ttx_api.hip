@@ -272,6 +272,7 @@ struct ttx_session {
   // snapshot of one verify step for the logits parity test (ttx_gen_params.want_logits)
   Buf snap_logits, snap_act, snap_front, snap_gen, snap_state;
   int snap_B = 0, snap_rps = 0, snap_gen_ld = 0, snap_step = 0;
+  Buf leaf_score, leaf_tok, leaf_cnt, beam_summary;
   // tree (beam) decoding
   Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of, t_len, t_parent, t_parent_draft, t_active;
   struct { int B = 0, Ls = 0, max_cand = 0, max_len = 0, N = 0, D = 0, Lc = 0, gen_ld = 0, cur = 0, prev_N = 1, prev_D = 0, steps = 0; } tree;
@@ -308,7 +309,8 @@ struct ttx_session {
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
                                  &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &tk[0], &tk[1], &tv[0], &tv[1],
                                  &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active, &dbg_gemm,
-                                 &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state}) all.push_back(b); }
+                                 &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state, &leaf_score, &leaf_tok, &leaf_cnt,
+                                 &beam_summary}) all.push_back(b); }
 };
 
 static thread_local uint64_t* g_alloc_gen = nullptr;   // alloc_generation of the session being sized
@@ -1350,6 +1352,51 @@ extern "C" int ttx_ragged_topk(ttx_session* s, const float* d_score, const int32
   RaggedTopkArgs a{d_score, d_offsets, k, d_top, d_idx};
   hipLaunchKernelGGL(k_ragged_topk, dim3(G), dim3(256), lds, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+// Candidate expansion of one beam-speculative iteration (`sample` + per-source top-n_best + row assembly:
+// speculative_decoding.py:294-400, :573-598).  h_summary (HOST, int32[5]): new candidates holding EOS, minimum PAD count
+// over the new rows, sum and count of the accepted-token marks >= 0, error flag (a source with fewer than K leaves).
+extern "C" int ttx_beam_expand(ttx_session* s, const float* d_cl, const int64_t* d_chosen, const int64_t* d_best_n,
+                               const float* d_logp, const int64_t* d_cand, int width, const int32_t* d_len,
+                               const int32_t* d_chosen_slot, const uint8_t* d_finished, int B, int beam, int dl, int V, int K,
+                               int pad, int bos, int eos, int64_t* d_new_cand, float* d_new_logp, int32_t* d_parent,
+                               int32_t* d_parent_draft, int32_t* d_mark, int32_t* h_summary, void* stream) {
+  if (!s || !d_cl || !d_chosen || !d_best_n || !d_logp || !d_cand || !d_len || !d_chosen_slot || !d_finished || !d_new_cand ||
+      !d_new_logp || !d_parent || !d_parent_draft || !d_mark || !h_summary)
+    return fail(TTX_ERR_INVALID, "null argument to ttx_beam_expand");
+  if (B <= 0 || beam <= 0 || dl <= 0 || V <= 0 || V > 64 * NUC_VPL || K < 1 || K > NUC_MAX_KEEP || width < dl + 2)
+    return fail(TTX_ERR_INVALID, "ttx_beam_expand: shape outside the kernels' limits");
+  const int dl1 = dl + 1, n_cand = B * beam;
+  const size_t L = (size_t)beam * dl1 * K;
+  if (beam * dl1 > 1023 || 2 * L * 4 > 150 * 1024) return fail(TTX_ERR_INVALID, "ttx_beam_expand: too many leaves per source for the LDS image");
+  HIP_TRY(hipSetDevice(s->m->device));
+  hipStream_t st = (hipStream_t)stream;
+  TTX_TRY(ensure(s->leaf_score, (size_t)n_cand * dl1 * K * 4, st));
+  TTX_TRY(ensure(s->leaf_tok, (size_t)n_cand * dl1 * K * 4, st));
+  TTX_TRY(ensure(s->leaf_cnt, (size_t)n_cand * dl1 * 4, st));
+  TTX_TRY(ensure(s->beam_summary, 8 * 4, st));
+  const int init[5] = {0, 0x7fffffff, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(s->beam_summary.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+  BeamLeavesArgs la{d_cl, d_chosen, d_best_n, d_logp, n_cand, dl, V, K, bos, s->leaf_score.as<float>(), s->leaf_tok.as<int>(),
+                    s->leaf_cnt.as<int>()};
+  hipLaunchKernelGGL(k_beam_leaves, dim3(n_cand), dim3(256), (size_t)2 * dl1 * 4, st, la);
+  HIP_TRY(hipGetLastError());
+  BeamSelectArgs sa{s->leaf_score.as<float>(), s->leaf_tok.as<int>(), s->leaf_cnt.as<int>(), d_cand, width, d_len, d_chosen,
+                    d_chosen_slot, d_finished, B, beam, dl, K, pad, eos, d_new_cand, d_new_logp, d_parent, d_parent_draft, d_mark,
+                    s->beam_summary.as<int>()};
+  const size_t lds = 2 * L * 4;
+  static bool attr = false;
+  if (lds > 64 * 1024 && !attr) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_beam_select), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_beam_select, dim3(B), dim3(256), lds, st, sa);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h_summary, s->beam_summary.p, 5 * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (h_summary[4]) return fail(TTX_ERR_REFERENCE, "a source has fewer candidate leaves than n_best (the reference asserts here, speculative_decoding.py:195)");
   return TTX_OK;
 }
 

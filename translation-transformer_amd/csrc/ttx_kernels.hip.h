@@ -1478,6 +1478,186 @@ __global__ __launch_bounds__(256) void k_ragged_topk(RaggedTopkArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Beam-speculative candidate expansion (SURVEY.md §2.3 K12 + K14; speculative_decoding.py:294-400 `sample`, :573-598).
+//   k_beam_leaves: one workgroup per candidate.  For every position p <= n_accepted of the candidate's chosen draft: the
+//     n_best largest logits (nucleus >= 1 mode) minus the accepted draft token (positions < n_accepted), minus <BOS> at
+//     the first rejected position, minus logits that are exactly 0 — each survivor is a leaf "keep p draft tokens, then
+//     this token".  Leaf score = log-prob of the root + log-softmax of the kept tokens summed in position order (fp32,
+//     sequential) + log-softmax of the leaf token.  Leaves are stored per (candidate, position) in ascending token id,
+//     which is the order torch.nonzero enumerates them in.
+//   k_beam_select: one workgroup per source.  The n_best best leaves of the source's candidates, best first (ties: earlier
+//     in enumeration order), and the rows of the new candidates: root tokens, the kept draft tokens, the leaf token.
+struct BeamLeavesArgs {
+  const float* cl;            // [n_cand, dl+1, V] logits along each candidate's chosen draft
+  const int64_t* chosen;      // [n_cand, dl]
+  const int64_t* best_n;      // [n_cand] accepted draft tokens
+  const float* logp;          // [n_cand]
+  int n_cand, dl, V, K, bos;
+  float* leaf_score; int* leaf_tok; int* leaf_cnt;   // [n_cand, dl+1, K], [n_cand, dl+1, K], [n_cand, dl+1]
+};
+
+__global__ __launch_bounds__(256) void k_beam_leaves(BeamLeavesArgs a) {
+  extern __shared__ float lp_kept[];          // [dl+1] log-softmax of the kept (chosen) token at every position
+  const int c = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int dl1 = a.dl + 1;
+  const int nacc = (int)a.best_n[c];
+  float* run = lp_kept + dl1;                 // [dl+1] sequential prefix sums
+  // pass 1: per position softmax statistics, kept-token log-prob, and the surviving top-K (unsorted ranks)
+  for (int p = wave; p < dl1; p += 4) {
+    const float* row = a.cl + ((size_t)c * dl1 + p) * a.V;
+    int ki[NUC_MAX_KEEP];
+    float kv[NUC_MAX_KEEP];
+    int nk = 0;
+    float m = -INFINITY, z = 0.f;
+    if (p <= nacc) {
+      nucleus_select(row, a.V, 20.0f, a.K, lane, ki, kv, nk);
+      float v[NUC_VPL];
+#pragma unroll
+      for (int i = 0; i < NUC_VPL; ++i) { const int col = lane + 64 * i; v[i] = col < a.V ? row[col] : -INFINITY; m = fmaxf(m, v[i]); }
+      m = wave_max(m);
+#pragma unroll
+      for (int i = 0; i < NUC_VPL; ++i) z += (lane + 64 * i < a.V) ? expf(v[i] - m) : 0.f;
+      z = wave_sum(z);
+    }
+    if (lane == 0) {
+      int cnt = 0;
+      if (p <= nacc) {
+        const int excl = (p < nacc) ? (int)a.chosen[(size_t)c * a.dl + p] : ((p < a.dl) ? a.bos : -1);
+        // ascending token id (insertion sort of <= 32 entries), dropping excluded tokens and exact-zero logits
+        for (int i = 0; i < nk; ++i) {
+          if (ki[i] == excl || kv[i] == 0.0f) continue;
+          int pos = cnt++;
+          float* ls = a.leaf_score + ((size_t)c * dl1 + p) * a.K;
+          int* lt = a.leaf_tok + ((size_t)c * dl1 + p) * a.K;
+          while (pos > 0 && lt[pos - 1] > ki[i]) { lt[pos] = lt[pos - 1]; ls[pos] = ls[pos - 1]; --pos; }
+          lt[pos] = ki[i];
+          ls[pos] = logf(expf(kv[i] - m) / z);         // log(softmax), as the reference writes it
+        }
+        lp_kept[p] = (p < nacc) ? logf(expf(row[(int)a.chosen[(size_t)c * a.dl + p]] - m) / z) : 0.f;
+      } else {
+        lp_kept[p] = 0.f;
+      }
+      a.leaf_cnt[(size_t)c * dl1 + p] = cnt;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {                      // run[p] = ((lp0 + lp1) + ...) + lp_{p-1}, summed in position order
+    float acc = 0.f;
+    for (int p = 0; p < dl1; ++p) { run[p] = acc; acc = (p == 0) ? lp_kept[0] : acc + lp_kept[p]; }
+  }
+  __syncthreads();
+  const float root = a.logp[c];
+  for (int e = threadIdx.x; e < dl1 * a.K; e += blockDim.x) {
+    const int p = e / a.K, i = e % a.K;
+    if (p <= nacc && i < a.leaf_cnt[(size_t)c * dl1 + p]) {
+      float* ls = a.leaf_score + ((size_t)c * dl1 + p) * a.K + i;
+      const float stepsum = (p == 0) ? *ls : run[p] + *ls;     // the torch path adds columns 0..p in order, then zeros
+      *ls = root + stepsum;
+    }
+  }
+}
+
+struct BeamSelectArgs {
+  const float* leaf_score; const int* leaf_tok; const int* leaf_cnt;
+  const int64_t* cand; int width;              // [n_cand, width] current rows (left-aligned, >= dl+1 PAD columns at the end)
+  const int* len;                              // [n_cand] real tokens per row
+  const int64_t* chosen; const int* chosen_slot;   // [n_cand, dl], [n_cand] draft slot of the chosen draft
+  const uint8_t* finished;                     // [n_cand] row already holds EOS
+  int B, beam, dl, K, pad, eos;
+  int64_t* new_cand; float* new_logp; int* parent; int* parent_draft; int* mark;   // [B*K, width], [B*K] ...
+  int* summary;                                // [4]: candidates with EOS, min PAD count, sum of marks >= 0, count of marks >= 0; [4] error
+};
+
+__global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs a) {
+  extern __shared__ float sh[];                // scores [L] then codes [L] (as int)
+  const int b = blockIdx.x;
+  const int dl1 = a.dl + 1;
+  const int L = a.beam * dl1 * a.K;            // strided capacity; entries beyond a (c,p) count hold -inf
+  float* sc = sh;
+  int* code = reinterpret_cast<int*>(sh + L);  // enumeration rank of each strided entry (for tie-breaking) or -1
+  __shared__ int s_off[1024];                  // exclusive prefix of leaf counts over (candidate, position) of this source
+  __shared__ float s_best[4];
+  __shared__ int s_bi[4];
+  __shared__ int s_sel;
+  const int nseg = a.beam * dl1;
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int sidx = 0; sidx < nseg; ++sidx) { s_off[sidx] = acc; acc += a.leaf_cnt[(size_t)b * nseg + sidx]; }
+    s_off[nseg] = acc;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < L; e += blockDim.x) {
+    const int seg = e / a.K, i = e % a.K;
+    const int cnt = a.leaf_cnt[(size_t)b * nseg + seg];
+    sc[e] = (i < cnt) ? a.leaf_score[((size_t)b * nseg + seg) * a.K + i] : -INFINITY;
+    code[e] = (i < cnt) ? s_off[seg] + i : 0x7fffffff;
+  }
+  __syncthreads();
+  if (s_off[nseg] < a.K) { if (threadIdx.x == 0) a.summary[4] = 1; return; }   // the reference asserts len >= k
+  for (int r = 0; r < a.K; ++r) {
+    float best = -INFINITY;
+    int bc = 0x7fffffff, be = -1;
+    for (int e = threadIdx.x; e < L; e += blockDim.x) {
+      const float v = sc[e];
+      const int cd = code[e];
+      if (cd != 0x7fffffff && (v > best || (v == best && cd < bc))) { best = v; bc = cd; be = e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oc = __shfl_xor(bc, o, 64);
+      const int oe = __shfl_xor(be, o, 64);
+      if (oc != 0x7fffffff && (ov > best || (ov == best && oc < bc) || bc == 0x7fffffff)) { best = ov; bc = oc; be = oe; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = best; s_bi[threadIdx.x >> 6] = be; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int sel = s_bi[0];
+      float bv = s_best[0];
+      for (int w = 1; w < 4; ++w) {
+        const int e2 = s_bi[w];
+        if (e2 < 0) continue;
+        if (sel < 0 || s_best[w] > bv || (s_best[w] == bv && code[e2] < code[sel])) { sel = e2; bv = s_best[w]; }
+      }
+      s_sel = sel;
+    }
+    __syncthreads();
+    const int sel = s_sel;
+    const int seg = sel / a.K, i = sel % a.K;
+    const int cl_local = seg / dl1, p = seg % dl1;
+    const int c = b * a.beam + cl_local;        // root candidate
+    const int out = b * a.K + r;                // new candidate index
+    const int tok = a.leaf_tok[((size_t)b * nseg + seg) * a.K + i];
+    const int lc = a.len[c];
+    const int64_t* root = a.cand + (size_t)c * a.width;
+    int64_t* dst = a.new_cand + (size_t)out * a.width;
+    for (int col = threadIdx.x; col < a.width; col += blockDim.x) {
+      int64_t t = root[col];
+      const int j = col - lc;
+      if (j >= 0 && j <= a.dl) t = (j < p) ? a.chosen[(size_t)c * a.dl + j] : (j == p ? (int64_t)tok : (int64_t)a.pad);
+      dst[col] = t;
+    }
+    if (threadIdx.x == 0) {
+      a.new_logp[out] = sc[sel];
+      a.parent[out] = c;
+      a.parent_draft[out] = a.chosen_slot[c];
+      const int fin_root = a.finished[c];
+      a.mark[out] = fin_root ? -1 : p;
+      const bool has_eos = fin_root || tok == a.eos;       // accepted draft tokens are never EOS (drafting.py:65)
+      if (has_eos) atomicAdd(&a.summary[0], 1);
+      // PAD columns of the new row: everything after its last real token
+      const int real = (tok == a.pad) ? lc + p : lc + p + 1;
+      atomicMin(&a.summary[1], a.width - real);
+      if (!fin_root) { atomicAdd(&a.summary[2], p); atomicAdd(&a.summary[3], 1); }
+      sc[sel] = -INFINITY;
+      code[sel] = 0x7fffffff;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tree (beam) decoding with a per-candidate KV cache: SURVEY.md §2.3 K12-K14's decoder side.  A "candidate" is one
 // hypothesis row (n_best per source); its cache is rebuilt every step from its parent's cache plus the parent's
 // accepted step rows, then the same verify-step kernels run with candidate = running row.

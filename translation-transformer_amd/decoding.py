@@ -398,6 +398,21 @@ class _BeamSearchSpeculativeHost:
             chosen = row_d[best_row].clone()
             cl = logits[best_row]
 
+            if native and kvdec is not None and beam * (dl + 1) <= 1023 and 8 * beam * (dl + 1) * K <= 150 * 1024 \
+                    and os.environ.get("TTX_BEAM_NATIVE_EXPAND", "1") != "0":
+                # K12 + K13 + K14 in two kernels: leaf enumeration/scoring per candidate, selection + row assembly per source
+                cand, logp, prev_parent, prev_pdraft, mark, summ = m.beam_expand(
+                    cl, chosen, best_n, logp, cand, (~pads).sum(-1), row_slot[best_row], (cand == EOS).any(dim=-1), B, beam, K,
+                    PAD, BOS, EOS)
+                self.accepted_tokens_num += summ[2]
+                self.produced_non_pad_tokens += summ[2] + summ[3]
+                if summ[0] == B * K:
+                    break
+                empty_cols = summ[1]
+                after_last = width - empty_cols
+                room = self.max_len - after_last - 1
+                continue
+
             pos = torch.arange(dl + 1, device=dev)
             topn = m.nucleus_mask(cl, 20.0, K, 0.0) if native else _nucleus(cl, 20.0, K, 0.0)
             tree = topn * (pos.unsqueeze(0) <= best_n.unsqueeze(1)).unsqueeze(-1)
