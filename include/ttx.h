@@ -31,7 +31,8 @@ typedef enum ttx_status {
   TTX_ERR_HIP = -2,          /* a HIP runtime call failed                                        */
   TTX_ERR_NO_DEVICE = -3,    /* no gfx950 device visible: the library has NO CPU fallback         */
   TTX_ERR_REFERENCE = -4,    /* input on which the reference itself raises (see ttx_last_error)  */
-  TTX_ERR_NOMEM = -5
+  TTX_ERR_NOMEM = -5,
+  TTX_ERR_ROW_REPLAY = -6    /* ttx_greedy_speculative_generate_rows only: decode the batches as given instead */
 } ttx_status;
 
 /* Model hyper-parameters: the init_args of VanillaTransformer (src/model/modules.py:11-38). */
@@ -194,6 +195,23 @@ int ttx_greedy_speculative_generate_many(ttx_session** sessions, int n_sessions,
                                          const int64_t* const* d_src, const int* B, const int* Ls,
                                          const ttx_gen_params* p, int64_t* const* d_out, ttx_gen_stats* stats,
                                          void* stream);
+
+/* Row-scheduled decoding (second half: batches regrouped by length).  The reference's loop
+ * couples the rows of a batch only through the shared width of `generated_tokens` (speculative_decoding.py:93,
+ * :97-102, :145, :158): the loop ends once max(front) + draft_len + 2 >= max_len, and a row finishing at a width
+ * beyond max_len raises.  Tokens, drafts and accepted lengths of a row do not depend on its neighbours.  This
+ * entry point therefore decodes every row under the rule it would see ALONE in a batch (continue while
+ * front + draft_len + 2 < max_len) and returns, besides d_out[i] (int64 [B_i][max_len]; rows that never produced
+ * EOS stay PAD), each row's front after every verify step: d_traj[i] int16 [B_i][max_len + 1] (column 0 = 0, -1
+ * past the row's last step) and d_fin_step[i] int32 [B_i] (the step that produced EOS, 0 = none).  From these a
+ * caller that regrouped rows (e.g. sorted by source length) replays the reference's width rule over the ORIGINAL
+ * batches and obtains exactly their outputs, errors and model-call counts; translation-transformer_amd/decoding.py
+ * `generate_many(..., reorder=True)` does that.  Returns TTX_ERR_ROW_REPLAY when a row emitted PAD inside its
+ * sequence (reference quirk: the outcome then depends on the neighbours; decode those batches as given). */
+int ttx_greedy_speculative_generate_rows(ttx_session** sessions, int n_sessions, int n_batches,
+                                         const int64_t* const* d_src, const int* B, const int* Ls,
+                                         const ttx_gen_params* p, int64_t* const* d_out, int16_t* const* d_traj,
+                                         int32_t* const* d_fin_step, ttx_gen_stats* stats, void* stream);
 
 /* Host-side string work either side of the hot path (no GPU) ------------------------------------
  * ChemSMILESTokenizer (src/data_handling/tokenizer_smiles.py:8-39), the pad_sequence collate

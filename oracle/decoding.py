@@ -126,6 +126,9 @@ class GreedySpeculativeOracle:
         # extra, oracle-only: totals and one record per verify step (roofline accounting of bench.py)
         self.accepted_total = 0
         self.step_log: list[tuple[int, int, int]] = []
+        # oracle-only: (running rows, their fronts) after every verify step of the last generate call —
+        # the per-row traces tests/test_row_scheduling.py replays
+        self.front_log: list[tuple[np.ndarray, np.ndarray]] = []
 
     def __str__(self):
         return (f"Greedy speculative decoding (draft_len={self.draft_len}, n_drafts={self.n_drafts}, "
@@ -143,6 +146,7 @@ class GreedySpeculativeOracle:
         Dd = drafts.shape[2]                                            # == D unless clamped by max_len
 
         result = np.full((B, self.max_len), PAD, dtype=np.int64)
+        self.front_log = []
         alive = np.arange(B)                                            # original indices of running rows
         gen = np.full((B, 1), self.bos_token, dtype=np.int64)           # [Bc, Lg]
         front = np.zeros(B, dtype=np.int64)                             # index of the last real token
@@ -184,6 +188,7 @@ class GreedySpeculativeOracle:
             np.put_along_axis(gen, front[:, None] + 1 + np.arange(Dd + 1)[None, :], chosen, axis=1)  # (:144-145)
             front = front + n_acc + 1
             self.accepted_total += int(n_acc.sum())
+            self.front_log.append((alive.copy(), front.copy()))
 
             done = (gen == EOS).any(axis=1)                              # (:149-168)
             if done.any():

@@ -105,6 +105,69 @@ def test_large_ragged_batch_matches_oracle(tta, tiny):
     assert "equal" in outcomes
 
 
+def _sequential(tta, model, batches, max_len, D, N, c):
+    """Per-batch `generate` calls: outputs (None where the reference raises), model calls of the batches that ran."""
+    outs, calls = [], []
+    for b in batches:
+        g = tta.TranslationInferenceGreedySpeculative(model, max_len, D, N, PAD, BOS, EOS, c)
+        try:
+            outs.append(g.generate(b))
+            calls.append(g.model_calls_num)
+        except tta.ReferenceError_:
+            outs.append(None)
+            calls.append(None)
+    return outs, calls
+
+
+@pytest.mark.parametrize("max_len,D,N", [(150, 10, 3), (150, 4, 2), (45, 4, 2), (45, 10, 3), (40, 4, 2), (30, 10, 3), (27, 4, 2),
+                                         (57, 4, 2), (20, 8, 2), (12, 6, 1)])
+def test_row_scheduled_decoding_replays_the_given_batches(tta, tiny, max_len, D, N):
+    """generate_many(reorder=True): rows decoded in length-sorted groups under the per-row width rule
+    (ttx_greedy_speculative_generate_rows), then the reference's loop replayed over the batches as given —
+    outputs, model_calls_num and the raise-or-not outcome equal per-batch `generate` calls."""
+    src, _, c, _ = fixture_tokens()
+    batches = []
+    for lo, hi in ((0, 3), (3, 4), (4, 8), (8, 10), (0, 10), (5, 9), (6, 7)):
+        sel = src[lo:hi]
+        batches.append(sel[:, :int((sel != PAD).sum(1).max())].cuda())
+    ref, calls = _sequential(tta, tiny, batches, max_len, D, N, c)
+    ok = [i for i, o in enumerate(ref) if o is not None]
+    bad = [i for i, o in enumerate(ref) if o is None]
+    for group_size, in_flight in ((4, 3), (3, 1), (32, 2)):
+        g = tta.TranslationInferenceGreedySpeculative(tiny, max_len, D, N, PAD, BOS, EOS, c)
+        out = g.generate_many([batches[i] for i in ok], in_flight=in_flight, reorder=True, group_size=group_size)
+        assert g.stats_total.get("device_model_calls", 0) > 0 or not ok        # the row path ran (no silent fallback)
+        for i, o in zip(ok, out):
+            assert torch.equal(o, ref[i]), f"batch {i} group_size {group_size}"
+        assert g.model_calls_num == sum(calls[i] for i in ok)
+        if bad:
+            with pytest.raises(tta.ReferenceError_):
+                g.generate_many(batches, in_flight=in_flight, reorder=True, group_size=group_size)
+    print(f"max_len={max_len} D={D} N={N}: {len(ok)} batches equal, {len(bad)} raise as in the reference")
+
+
+def test_row_scheduled_decoding_random_sources(tta, tiny):
+    """320 ragged random sources in batches of 32.  Random token soup makes the tiny model emit PAD inside
+    sequences now and then (reference quirk 2): the row path reports that and generate_many decodes the batches
+    as given instead; either way the result equals per-batch generate."""
+    _, _, c, V = fixture_tokens()
+    src = _random_sources(320, 6, 60, V, seed=11)
+    batches = []
+    for i in range(0, 320, 32):
+        sel = src[i:i + 32]
+        batches.append(sel[:, :int((sel != PAD).sum(1).max())].cuda())
+    for max_len, D, N in ((150, 10, 3), (64, 4, 2)):
+        ref, calls = _sequential(tta, tiny, batches, max_len, D, N, c)
+        ok = [i for i, o in enumerate(ref) if o is not None]
+        g = tta.TranslationInferenceGreedySpeculative(tiny, max_len, D, N, PAD, BOS, EOS, c)
+        out = g.generate_many([batches[i] for i in ok], in_flight=4, reorder=True)
+        for i, o in zip(ok, out):
+            assert torch.equal(o, ref[i])
+        assert g.model_calls_num == sum(calls[i] for i in ok)
+        print(f"random sources max_len={max_len}: {len(ok)}/10 batches decodable, row path used:",
+              "device_model_calls" in g.stats_total)
+
+
 def test_streaming_attention_fallback_matches(tta):
     """The long-sequence attention kernel (k_attn, used when the LDS images of k_attn2 do not fit) on the same
     inputs as the fast path."""

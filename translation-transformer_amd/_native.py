@@ -17,6 +17,7 @@ LIB_PATH = PKG_DIR / "libttx_hip.so"
 SOURCES = [CSRC / "ttx_api.hip", CSRC / "ttx_kernels.hip.h", CSRC / "ttx_tokenizer.h", INCLUDE / "ttx.h"]
 
 TTX_OK, TTX_ERR_INVALID, TTX_ERR_HIP, TTX_ERR_NO_DEVICE, TTX_ERR_REFERENCE, TTX_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+TTX_ERR_ROW_REPLAY = -6
 
 
 class TtxError(RuntimeError):
@@ -73,6 +74,9 @@ SYMBOLS = {
     "ttx_greedy_speculative_generate_many": (C.c_int, [C.POINTER(_VP), _I, _I, C.POINTER(_VP), C.POINTER(C.c_int),
                                                       C.POINTER(C.c_int), C.POINTER(GenParams), C.POINTER(_VP),
                                                       C.POINTER(GenStats), _VP]),
+    "ttx_greedy_speculative_generate_rows": (C.c_int, [C.POINTER(_VP), _I, _I, C.POINTER(_VP), C.POINTER(C.c_int),
+                                                      C.POINTER(C.c_int), C.POINTER(GenParams), C.POINTER(_VP),
+                                                      C.POINTER(_VP), C.POINTER(_VP), C.POINTER(GenStats), _VP]),
     "ttx_nucleus_mask": (C.c_int, [_VP, _VP, _I, _I, C.c_float, _I, C.c_float, _VP, _VP]),
     "ttx_accepted_lengths": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _I, _VP, _VP]),
     "ttx_ragged_topk": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),

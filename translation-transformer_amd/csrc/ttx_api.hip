@@ -252,7 +252,7 @@ struct Buf {
 };
 
 struct GraphKey {
-  int B, Ls, N, D, max_len, greedy, kcap;
+  int B, Ls, N, D, max_len, greedy, kcap;   // greedy: 0 speculative, 1 plain greedy, 2 speculative under the per-row rule
   bool operator<(const GraphKey& o) const {
     return std::tie(B, Ls, N, D, max_len, greedy, kcap) < std::tie(o.B, o.Ls, o.N, o.D, o.max_len, o.greedy, o.kcap);
   }
@@ -268,7 +268,7 @@ struct ttx_session {
   // full decoder
   Buf tok_tgt, mem_pad_tmp;
   // loop
-  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf, dbg_self, dbg_cross, haspad;
+  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf, dbg_self, dbg_cross, haspad, traj, fin_step;
   // snapshot of one verify step for the logits parity test (ttx_gen_params.want_logits)
   Buf snap_logits, snap_act, snap_front, snap_gen, snap_state;
   int snap_B = 0, snap_rps = 0, snap_gen_ld = 0, snap_step = 0;
@@ -307,7 +307,7 @@ struct ttx_session {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
   ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
-                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &tk[0], &tk[1], &tv[0], &tv[1],
+                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &traj, &fin_step, &tk[0], &tk[1], &tv[0], &tv[1],
                                  &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active, &dbg_gemm,
                                  &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state, &leaf_score, &leaf_tok, &leaf_cnt,
                                  &beam_summary}) all.push_back(b); }
@@ -810,6 +810,8 @@ struct GenJob {
   GenCtx g{};
   bool greedy = false;
   int64_t* d_out = nullptr;
+  int16_t* d_traj = nullptr;     // per-row rule only: [B][max_len + 1] fronts after every step (-1 past the row's last step)
+  int32_t* d_fin = nullptr;      // per-row rule only: [B] step at which the row produced EOS (0: never)
   ttx_gen_stats* stats = nullptr;
   int launched = 0;
   int phase = 0;          // 0 idle, 1 running, 2 finishing
@@ -837,13 +839,15 @@ static int gen_validate(const ttx_session* s, const int64_t* d_src, int B, int L
 }
 
 static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p,
-                     int64_t* d_out, ttx_gen_stats* stats, bool greedy) {
+                     int64_t* d_out, ttx_gen_stats* stats, bool greedy, int16_t* d_traj = nullptr, int32_t* d_fin = nullptr) {
   const ttx_model* m = s->m;
   const ttx_config& c = m->cfg;
   const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
   const int N = greedy ? 1 : p->n_drafts, D = greedy ? 0 : p->draft_len, D1 = D + 1;
   const int max_len = p->max_len;
   j.s = s; j.st = st; j.greedy = greedy; j.d_out = d_out; j.stats = stats; j.launched = 0;
+  j.d_traj = d_traj; j.d_fin = d_fin;
+  const bool row_rule = d_traj != nullptr;
   s->snap_step = 0;
   GenCtx& g = j.g;
   g = GenCtx{};
@@ -863,6 +867,10 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   TTX_TRY(ensure(s->front, (size_t)B * 4, st));
   TTX_TRY(ensure(s->act_idx, (size_t)B * 4, st));
   TTX_TRY(ensure(s->haspad, (size_t)B * 4, st));
+  if (row_rule) {
+    TTX_TRY(ensure(s->traj, (size_t)B * (max_len + 1) * 2, st));
+    TTX_TRY(ensure(s->fin_step, (size_t)B * 4, st));
+  }
   TTX_TRY(ensure(s->rec, (size_t)B * sizeof(CopyRec), st));
   TTX_TRY(ensure(s->pred, Mmax * 4, st));
   TTX_TRY(ensure(s->state, sizeof(DecState), st));
@@ -908,6 +916,8 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   g.la.host = dev_info;
   g.la.B = B; g.la.N = N; g.la.D = D; g.la.Ls = Ls; g.la.max_len = max_len; g.la.pad = p->pad_token; g.la.bos = p->bos_token;
   g.la.eos = p->eos_token;
+  g.la.row_rule = row_rule ? 1 : 0; g.la.traj = row_rule ? s->traj.as<short>() : nullptr; g.la.traj_ld = max_len + 1;
+  g.la.fin_step = row_rule ? s->fin_step.as<int>() : nullptr;
   g.kc.st = s->state.as<DecState>(); g.kc.rec = s->rec.as<CopyRec>(); g.kc.qkv = s->qkv.as<float>();
   g.kc.qkv_layer_stride = (long long)Mmax * 3 * d;
   g.kc.kcache = s->kcache.as<float>(); g.kc.vcache = s->vcache.as<float>();
@@ -955,7 +965,7 @@ static int gen_launch_step(GenJob& j, int width_bound) {
     ++j.launched;
     return TTX_OK;
   }
-  GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, j.greedy ? 1 : 0, kcap};
+  GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, j.greedy ? 1 : (j.g.la.row_rule ? 2 : 0), kcap};
   auto it = s->graphs.find(key);
   if (it == s->graphs.end()) {
     if (!s->warmed.count(key)) {
@@ -1001,6 +1011,10 @@ static int gen_finish_enqueue(GenJob& j) {
     HIP_TRY(hipGetLastError());
   } else {
     HIP_TRY(hipMemcpyAsync(j.d_out, s->outbuf.as<int64_t>(), (size_t)k.B * k.max_len * 8, hipMemcpyDeviceToDevice, j.st));
+    if (j.d_traj) {
+      HIP_TRY(hipMemcpyAsync(j.d_traj, s->traj.p, (size_t)k.B * (k.max_len + 1) * 2, hipMemcpyDeviceToDevice, j.st));
+      HIP_TRY(hipMemcpyAsync(j.d_fin, s->fin_step.p, (size_t)k.B * 4, hipMemcpyDeviceToDevice, j.st));
+    }
   }
   HIP_TRY(hipEventRecord(s->ev_c, j.st));
   HIP_TRY(hipMemcpyAsync(s->host_state, s->state.as<DecState>(), sizeof(DecState), hipMemcpyDeviceToHost, j.st));
@@ -1090,6 +1104,9 @@ static int gen_finish_collect(GenJob& j) {
     }
   }
   j.phase = 0;
+  if (hs.error == 3)
+    return fail(TTX_ERR_ROW_REPLAY, "a row emitted PAD inside its sequence: what the reference does next depends on the other rows "
+                                    "of its batch, so the batch must be decoded as given (ttx_greedy_speculative_generate_many)");
   if (hs.error == 2)
     return fail(TTX_ERR_REFERENCE, "the model emitted PAD inside a sequence and a whole column became PAD: the reference's draft "
                                    "scatter raises 'index out of range' here (speculative_decoding.py:97,111-115)");
@@ -1145,12 +1162,14 @@ extern "C" int ttx_greedy_generate(ttx_session* s, const int64_t* d_src, int B, 
 // Several batches in flight on one GPU: batch i is decoded on session i % n_sessions, each
 // session on its own stream; one host thread round-robins over the sessions, enqueueing the next verify step of
 // whichever session has published its previous one.  Outputs per batch are identical to the one-at-a-time call.
-extern "C" int ttx_greedy_speculative_generate_many(ttx_session** sessions, int n_sessions, int n_batches,
-                                                    const int64_t* const* d_src, const int* B, const int* Ls,
-                                                    const ttx_gen_params* p, int64_t* const* d_out, ttx_gen_stats* stats,
-                                                    void* stream) {
+static int generate_many_impl(ttx_session** sessions, int n_sessions, int n_batches, const int64_t* const* d_src, const int* B,
+                              const int* Ls, const ttx_gen_params* p, int64_t* const* d_out, int16_t* const* d_traj,
+                              int32_t* const* d_fin, ttx_gen_stats* stats, void* stream) {
   if (!sessions || n_sessions <= 0 || n_batches < 0 || !d_src || !B || !Ls || !p || !d_out)
     return fail(TTX_ERR_INVALID, "bad argument to ttx_greedy_speculative_generate_many");
+  if (d_traj)
+    for (int i = 0; i < n_batches; ++i)
+      if (!d_traj[i] || !d_fin || !d_fin[i]) return fail(TTX_ERR_INVALID, "missing trace buffer for a batch");
   for (int i = 0; i < n_batches; ++i) TTX_TRY(gen_validate(sessions[0], d_src[i], B[i], Ls[i], p, d_out[i], false));
   HIP_TRY(hipSetDevice(sessions[0]->m->device));
   hipStream_t caller = (hipStream_t)stream;
@@ -1174,7 +1193,8 @@ extern "C" int ttx_greedy_speculative_generate_many(ttx_session** sessions, int 
         if (next < n_batches) {
           j.batch = next++;
           int rc = gen_start(j, s, s->own_stream, d_src[j.batch], B[j.batch], Ls[j.batch], p, d_out[j.batch],
-                             stats ? &stats[j.batch] : nullptr, false);
+                             stats ? &stats[j.batch] : nullptr, false, d_traj ? d_traj[j.batch] : nullptr,
+                             d_traj ? d_fin[j.batch] : nullptr);
           if (rc != TTX_OK) { rc_final = rc; done = n_batches; break; }
           progressed = true;
         }
@@ -1209,6 +1229,25 @@ extern "C" int ttx_greedy_speculative_generate_many(ttx_session** sessions, int 
   // later work on the caller's stream must see the outputs
   (void)hipEventDestroy(ready);
   return rc_final;
+}
+
+extern "C" int ttx_greedy_speculative_generate_many(ttx_session** sessions, int n_sessions, int n_batches,
+                                                    const int64_t* const* d_src, const int* B, const int* Ls,
+                                                    const ttx_gen_params* p, int64_t* const* d_out, ttx_gen_stats* stats,
+                                                    void* stream) {
+  return generate_many_impl(sessions, n_sessions, n_batches, d_src, B, Ls, p, d_out, nullptr, nullptr, stats, stream);
+}
+
+// The same engine under the per-row width rule: rows neither wait for nor are cut short by the other rows of their
+// device batch, and each row's front after every step is returned, so the caller may group rows by length and still
+// reproduce, batch by batch, what the reference's loop does to the batches it was given (decoding.py replays it).
+extern "C" int ttx_greedy_speculative_generate_rows(ttx_session** sessions, int n_sessions, int n_batches,
+                                                    const int64_t* const* d_src, const int* B, const int* Ls,
+                                                    const ttx_gen_params* p, int64_t* const* d_out, int16_t* const* d_traj,
+                                                    int32_t* const* d_fin_step, ttx_gen_stats* stats, void* stream) {
+  if (!d_traj || !d_fin_step) return fail(TTX_ERR_INVALID, "ttx_greedy_speculative_generate_rows needs the trace buffers");
+  if (p && p->max_len > 32000) return fail(TTX_ERR_INVALID, "max_len too large for the int16 trace");
+  return generate_many_impl(sessions, n_sessions, n_batches, d_src, B, Ls, p, d_out, d_traj, d_fin_step, stats, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

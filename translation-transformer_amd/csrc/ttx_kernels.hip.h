@@ -35,7 +35,7 @@ struct DecState {
   long long accepted, produced, verified_positions, kv_prefix_positions, src_positions;
 };
 
-struct CopyRec { int b, best, nacc, front_old; };
+struct CopyRec { int b, best, nacc, front_old, flags; };   // flags: 1 finished this step, 2 retired without finishing
 
 // Host-mapped (pinned) words the accept kernels publish after every step; the host polls them instead of
 // synchronising the stream.
@@ -1125,6 +1125,9 @@ struct LoopArgs {
   DecState* st; int* act_idx; int* front; int* gen; int gen_ld;
   const int* drafts; const int* pred;
   CopyRec* rec; int64_t* out; HostInfo* host; int* haspad;
+  // per-row width rule (ttx_gen_params.row_rule): every row decodes as if it were alone in its batch and its front after
+  // every step is recorded, so a scheduler may regroup rows freely and still reproduce each original batch exactly
+  int row_rule; short* traj; int traj_ld; int* fin_step;
   int B, N, D, Ls, max_len, pad, bos, eos;
 };
 
@@ -1133,7 +1136,12 @@ __global__ void k_loop_init(LoopArgs a) {
   const int total = a.B * a.gen_ld;
   for (int i = tid; i < total; i += gridDim.x * blockDim.x) a.gen[i] = (i % a.gen_ld == 0) ? a.bos : a.pad;
   for (int i = tid; i < a.B * a.max_len; i += gridDim.x * blockDim.x) a.out[i] = a.pad;
-  for (int i = tid; i < a.B; i += gridDim.x * blockDim.x) { a.act_idx[i] = i; a.front[i] = 0; a.haspad[i] = 0; }
+  for (int i = tid; i < a.B; i += gridDim.x * blockDim.x) {
+    a.act_idx[i] = i; a.front[i] = 0; a.haspad[i] = 0;
+    if (a.row_rule) a.fin_step[i] = 0;
+  }
+  if (a.row_rule)
+    for (int i = tid; i < a.B * a.traj_ld; i += gridDim.x * blockDim.x) a.traj[i] = (i % a.traj_ld == 0) ? 0 : -1;
   if (tid == 0) {
     DecState s;
     s.n_active = a.B; s.r_rows = a.B * a.N; s.m_rows = a.B * step_rps(a.N, a.D);
@@ -1185,8 +1193,15 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     }
     if (sawpad) a.haspad[b] = 1;
     a.front[b] = f + bacc + 1;
-    // the reference tests the whole row for EOS (:149); earlier positions cannot hold it (the row would have retired)
-    a.rec[slot] = CopyRec{fin ? -(b + 1) : b, best, bacc, f};      // negative b marks "finished this step"
+    int flags = fin ? 1 : 0;
+    if (a.row_rule) {
+      const int it = st->steps + 1;                    // all rows of this device batch started together
+      if (it < a.traj_ld) a.traj[(size_t)b * a.traj_ld + it] = (short)(f + bacc + 1);
+      if (fin) a.fin_step[b] = it;
+      // alone in a batch this row would see width f + D + 2 after this step and stop once that reaches max_len (:93)
+      else if (f + D1 + 1 >= a.max_len) flags = 2;
+    }
+    a.rec[slot] = CopyRec{b, best, bacc, f, flags};
     atomicMax(&s_maxfront, f);
     atomicAdd((unsigned long long*)&s_acc, (unsigned long long)bacc);
     atomicAdd((unsigned long long*)&s_prefix, (unsigned long long)f);
@@ -1200,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
   for (int base = 0; base < Bc; base += blockDim.x) {
     const int slot = base + threadIdx.x;
     const int code = slot < Bc ? a.rec[slot].b : -1;
-    const int keep = (slot < Bc && code >= 0) ? 1 : 0;
+    const int keep = (slot < Bc && a.rec[slot].flags == 0) ? 1 : 0;
     s_scan[threadIdx.x] = keep;
     __syncthreads();
     for (int off = 1; off < blockDim.x; off <<= 1) {   // inclusive Hillis-Steele scan over <= 256 flags
@@ -1217,17 +1232,15 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     nn_before += s_scan[blockDim.x - 1];
     __syncthreads();
   }
+  const int wout = a.row_rule ? a.max_len : wcopy;    // columns past a row's front are PAD either way
   for (int slot = 0; slot < Bc; ++slot) {
-    const int code = a.rec[slot].b;                 // uniform over the block
-    if (code < 0) {
-      const int b = -code - 1;
+    if (a.rec[slot].flags == 1) {                   // uniform over the block
+      const int b = a.rec[slot].b;
       const int* g = a.gen + (size_t)b * a.gen_ld;
-      for (int c = threadIdx.x; c < wcopy; c += blockDim.x) a.out[(size_t)b * a.max_len + c] = g[c];
+      for (int c = threadIdx.x; c < wout; c += blockDim.x) a.out[(size_t)b * a.max_len + c] = g[c];
     }
   }
   __syncthreads();
-  for (int slot = threadIdx.x; slot < Bc; slot += blockDim.x)
-    if (a.rec[slot].b < 0) a.rec[slot].b = -a.rec[slot].b - 1;
   if (threadIdx.x == 0) {
     const int nn = nn_before;
     st->n_copy = Bc;
@@ -1238,9 +1251,10 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     st->kv_prefix_positions += s_prefix;
     st->src_positions += (long long)Bc * a.Ls;
     st->width = width;
-    if (s_anyfin && width > a.max_len) st->error = 1;
-    int stop = (nn == 0 || width >= a.max_len) ? 1 : 0;
-    if (!stop && s_suspect) {
+    if (s_anyfin && width > a.max_len && !a.row_rule) st->error = 1;
+    int stop = (nn == 0 || (!a.row_rule && width >= a.max_len)) ? 1 : 0;
+    if (a.row_rule && s_suspect) st->error = 3;     // a PAD inside a sequence: per-batch quirks cannot be replayed from rows
+    if (!stop && s_suspect && !a.row_rule) {
       // Reference quirk 2 (speculative_decoding.py:97,111-115): if some column up to the longest running row's
       // front is PAD in every running row, the reference under-sizes its padded tensor and the draft scatter
       // raises.  Only possible when a running row holds a PAD token, so this scan almost never runs.
@@ -1280,7 +1294,7 @@ __global__ __launch_bounds__(256) void k_greedy_accept(LoopArgs a) {
     const int t = a.pred[b];
     a.gen[(size_t)b * a.gen_ld + f + 1] = t;
     a.front[b] = f + 1;
-    a.rec[b] = CopyRec{b, 0, 0, f};
+    a.rec[b] = CopyRec{b, 0, 0, f, 0};
     if (t != a.eos && t != a.pad) s_running = 1;
   }
   __syncthreads();

@@ -79,13 +79,24 @@ class TranslationInferenceGreedySpeculative:
         self.last_stats = st
         return out
 
-    def generate_many(self, batches: list, in_flight: int = 4) -> list:
+    def generate_many(self, batches: list, in_flight: int = 4, reorder: bool = False, group_size: int | None = None) -> list:
         """Decode several batches with up to `in_flight` of them on the GPU at once (one session + stream each;
         ttx_greedy_speculative_generate_many).  Returns one [B,1,max_len] tensor per batch, each identical to what
-        ``generate`` returns for that batch; counters accumulate as if ``generate`` had been called per batch."""
+        ``generate`` returns for that batch; counters accumulate as if ``generate`` had been called per batch.
+
+        ``reorder=True`` decodes the rows in groups sorted by source length (less padding, rows of similar length
+        finish together) through ttx_greedy_speculative_generate_rows and then replays the reference's width rule
+        over the batches as passed (scheduling.replay_batch): outputs, ``model_calls_num`` and the error behaviour
+        stay those of per-batch ``generate`` calls."""
         m = self.model
         if not batches:
             return []
+        if reorder:
+            try:
+                return self._generate_reordered(batches, in_flight, group_size)
+            except N.TtxError as e:
+                if e.code != N.TTX_ERR_ROW_REPLAY:
+                    raise            # otherwise: a PAD inside a sequence; decode the batches as given
         srcs = [b.to(m.device, torch.int64).contiguous() for b in batches]
         outs = [torch.empty((s.shape[0], 1, self.max_len), dtype=torch.int64, device=m.device) for s in srcs]
         n = len(srcs)
@@ -108,6 +119,84 @@ class TranslationInferenceGreedySpeculative:
                 t[k] += getattr(st, k)
             t["src_tokens_padded"] += srcs[i].shape[0] * srcs[i].shape[1]
             t["batches"] += 1
+        return outs
+
+    def _generate_reordered(self, batches: list, in_flight: int, group_size: int | None) -> list:
+        from .scheduling import plan_row_groups, replay_batch
+        m = self.model
+        L, T = self.max_len, self.max_len + 1
+        srcs = [b.to(m.device, torch.int64) for b in batches]
+        sizes = [int(s.shape[0]) for s in srcs]
+        R = sum(sizes)
+        gsz = int(group_size or max(sizes))
+        # all rows in one right-padded matrix; a row's length is the position after its last non-PAD token
+        Lmax = max(int(s.shape[1]) for s in srcs)
+        allsrc = torch.full((R, Lmax), self.pad_token, dtype=torch.int64, device=m.device)
+        r0 = 0
+        for s in srcs:
+            allsrc[r0:r0 + s.shape[0], :s.shape[1]] = s
+            r0 += s.shape[0]
+        pos = torch.arange(1, Lmax + 1, device=m.device)
+        lengths = ((allsrc != self.pad_token) * pos).amax(dim=1)
+        order, groups = plan_row_groups(lengths.cpu().numpy(), gsz)
+        order_t = torch.from_numpy(order).to(m.device)
+        sorted_src = allsrc[order_t]
+        sorted_len = lengths[order_t].cpu().numpy()
+        gsrc = [sorted_src[g, :max(2, int(sorted_len[g].max()))].contiguous() for g in groups]
+        n = len(gsrc)
+        out_sorted = torch.empty((R, L), dtype=torch.int64, device=m.device)
+        traj_sorted = torch.empty((R, T), dtype=torch.int16, device=m.device)
+        fin_sorted = torch.empty((R,), dtype=torch.int32, device=m.device)
+        pool = m.session_pool(max(1, min(in_flight, n)))
+        sess = (C.c_void_p * len(pool))(*[p.value for p in pool])
+        src_p = (C.c_void_p * n)(*[s.data_ptr() for s in gsrc])
+        out_p = (C.c_void_p * n)(*[out_sorted[g].data_ptr() for g in groups])
+        traj_p = (C.c_void_p * n)(*[traj_sorted[g].data_ptr() for g in groups])
+        fin_p = (C.c_void_p * n)(*[fin_sorted[g].data_ptr() for g in groups])
+        Bs = (C.c_int * n)(*[s.shape[0] for s in gsrc])
+        Ls = (C.c_int * n)(*[s.shape[1] for s in gsrc])
+        p = N.GenParams(L, self.draft_len, self.n_drafts, self.pad_token, self.bos_token, self.eos_token, self.replace_token, 0)
+        stats = (N.GenStats * n)()
+        N.check(m._lib.ttx_greedy_speculative_generate_rows(sess, len(pool), n, src_p, Bs, Ls, C.byref(p), out_p, traj_p, fin_p,
+                                                            stats, m._stream()))
+        # back to the caller's row order, then the reference's per-batch loop over the traces
+        inv = torch.empty_like(order_t)
+        inv[order_t] = torch.arange(R, device=m.device)
+        out_rows = out_sorted[inv]
+        traj = traj_sorted[inv].cpu().numpy()
+        fin = fin_sorted[inv].cpu().numpy()
+        keep = torch.zeros(R, dtype=torch.bool)
+        t = self.stats_total
+        failed = None
+        r0 = 0
+        for bi, B in enumerate(sizes):
+            rep = replay_batch(traj[r0:r0 + B], fin[r0:r0 + B], L, self.draft_len, self.n_drafts)
+            if rep.error:
+                failed = bi
+                break
+            keep[r0:r0 + B] = torch.from_numpy(rep.finished)
+            self.model_calls_num += rep.model_calls
+            t["accepted_tokens"] += rep.accepted_tokens
+            t["produced_tokens"] += rep.produced_tokens
+            t["verified_positions"] += rep.verified_positions
+            t["kv_prefix_positions"] += rep.kv_prefix_positions
+            t["src_positions"] += rep.rows_iterations * int(srcs[bi].shape[1])
+            t["src_tokens_padded"] += B * int(srcs[bi].shape[1])
+            t["batches"] += 1
+            r0 += B
+        for st in stats:
+            t["encode_ms"] += st.encode_ms
+            t["decode_ms"] += st.decode_ms
+        t["device_model_calls"] = t.get("device_model_calls", 0) + sum(int(st.model_calls) for st in stats)
+        t["device_src_tokens_padded"] = t.get("device_src_tokens_padded", 0) + sum(int(s.numel()) for s in gsrc)
+        if failed is not None:
+            raise N.ReferenceError_(f"batch {failed}: a row finished at a width beyond max_len: shape mismatch in the reference "
+                                    "(speculative_decoding.py:158)")
+        out_rows = torch.where(keep.to(m.device)[:, None], out_rows, torch.full_like(out_rows, self.pad_token))
+        outs, r0 = [], 0
+        for B in sizes:
+            outs.append(out_rows[r0:r0 + B].unsqueeze(1).contiguous())
+            r0 += B
         return outs
 
 
