@@ -37,7 +37,7 @@ BASELINE_REACTIONS_PER_S = 47.97  # BASELINE.md §1, bs=32 D=10 N=3 (reference's
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--draft-len", type=int, default=10)
@@ -45,10 +45,14 @@ def parse():
     ap.add_argument("--max-len", type=int, default=200)
     ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "1500")))
     ap.add_argument("--cpu-batches", type=int, default=1, help="batches of the workload timed on the host cores")
+    ap.add_argument("--schedule", choices=("rows", "batches"), default=os.environ.get("TTX_SCHEDULE", "rows"),
+                    help="rows: regroup the rows of the given batches by length (exact replay per batch); batches: as given")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("TTX_INFLIGHT", "8")),
                     help="batches decoded concurrently per GPU (1 = the reference's one-batch-at-a-time loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="skip the comparison passes (as-given, one at a time, event profile, CPU baseline): for rocprofv3 runs")
     return ap.parse_args()
 
 
@@ -111,6 +115,8 @@ def flops_and_bytes(cfg: dict, stats: dict, B_total_src_tokens: int, n_batches: 
 
 def main():
     a = parse()
+    if a.timed_only:
+        a.no_profile = a.no_cpu_baseline = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,12 +153,16 @@ def main():
     def make_gen(m):
         return tta.TranslationInferenceGreedySpeculative(m, a.max_len, a.draft_len, a.n_drafts, PAD, BOS, EOS, C_TOK)
 
+    # "rows": the K given batches are decoded as length-sorted row groups and replayed per given batch (exact);
+    # "batches": every given batch is decoded as given.  Both keep a.inflight groups/batches on the GPU at once.
+    rows_sched = a.schedule == "rows" and a.inflight > 1
     gen = make_gen(model)
     log("model ready; warmup")
     for b in warm:
         gen.generate(b)
-    if a.inflight > 1:     # warm every session of the pool (workspaces, graph capture)
-        gen.generate_many(warm * a.inflight, in_flight=a.inflight)
+    if a.inflight > 1:     # warm every session of the pool (workspaces, graph capture) at the timed region's grouping
+        reps = max(a.inflight, -(-len(timed) // max(1, len(warm)))) if rows_sched else a.inflight
+        gen.generate_many((warm * reps)[:max(a.inflight, len(timed))], in_flight=a.inflight, reorder=rows_sched)
     log("warmup done", gen.model_calls_num, "calls")
     gen = make_gen(model)
     torch.cuda.synchronize()
@@ -161,7 +171,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if a.inflight > 1:
-        outs = gen.generate_many(timed, in_flight=a.inflight)
+        outs = gen.generate_many(timed, in_flight=a.inflight, reorder=rows_sched)
     else:
         outs = [gen.generate(b) for b in timed]
     torch.cuda.synchronize()
@@ -194,18 +204,23 @@ def main():
                                f"n_drafts={a.n_drafts} bs={a.batch_size} max_len={a.max_len}, d=256 8h FFN2048 4+4 fp32, "
                                f"weights trained {a.train_steps} steps on the synthetic task",
                    "reactions": n_reactions, "parallelism": f"test-set shards x{world}, no per-step collective",
-                   "batches_in_flight_per_gpu": a.inflight},
+                   "batches_in_flight_per_gpu": a.inflight,
+                   "schedule": ("rows of the K given batches regrouped by source length on the device, reference loop replayed "
+                                "per given batch (outputs and model_calls identical to per-batch generate)") if rows_sched
+                               else "batches decoded as given"},
         "model_calls": stats["model_calls"], "rows_finished_rank0": finished, "rows_rank0": int(preds.shape[0]),
         "accepted_per_step_per_row": stats["accepted_tokens"] / max(1, stats["produced_tokens"] - stats["accepted_tokens"]),
         "device_ms_encode_rank0": stats["encode_ms"], "device_ms_decode_rank0": stats["decode_ms"],
     }
 
     if rank == 0:
-        work = flops_and_bytes(cfg, stats, stats["src_tokens_padded"], len(timed))
+        # work the device executed: under the row schedule that is the row groups', not the given batches'
+        dstats = dict(stats["device"], encode_ms=stats["encode_ms"], decode_ms=stats["decode_ms"]) if rows_sched else stats
+        work = flops_and_bytes(cfg, dstats, dstats["src_tokens_padded"], dstats.get("batches", len(timed)))
         line["hbm_algorithmic"] = {"bytes_per_reaction": work["bytes"] / (len(timed) * a.batch_size),
                                    "achieved_GBs": work["bytes"] / elapsed / 1e9,
                                    "frac_of_peak": work["bytes"] / elapsed / 1e9 / PEAK_HBM_GBS}
-        if a.inflight > 1:
+        if a.inflight > 1 and not a.timed_only:
             # the same K batches strictly one at a time (the reference's predict loop), for comparison
             g1 = make_gen(model)
             torch.cuda.synchronize()
@@ -214,31 +229,20 @@ def main():
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t1
             line["one_batch_at_a_time"] = {"value": len(timed) * a.batch_size / dt1, "unit": "reactions/s",
-                                           "identical_to_in_flight_outputs": all(torch.equal(x, y) for x, y in zip(seq, outs))}
-        if os.environ.get("TTX_BENCH_SORTED", "1") == "1":
-            # what length-bucketed batching (the scheduling DESIGN.md §8 item 3 names) would buy on the same reactions:
-            # same sequences, batches formed after sorting by source length; per-reaction outputs are identical
-            order = sorted(range(len(mine) - a.warmup * a.batch_size), key=lambda i: len(mine[a.warmup * a.batch_size + i]))
-            pool = [mine[a.warmup * a.batch_size + i] for i in order]
-            sb = [torch.from_numpy(b).to(dev) for b in batches(pool, a.batch_size)]
-            gs = make_gen(model)
-            gs.generate_many(sb[:a.inflight], in_flight=a.inflight)
-            gs = make_gen(model)
+                                           "identical_to_timed_outputs": all(torch.equal(x, y) for x, y in zip(seq, outs))}
+        if rows_sched and not a.timed_only:
+            # the same K batches decoded as given (no regrouping), a.inflight of them at a time
+            g2 = make_gen(model)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            so = gs.generate_many(sb, in_flight=a.inflight) if a.inflight > 1 else [gs.generate(b) for b in sb]
+            given = g2.generate_many(timed, in_flight=a.inflight)
             torch.cuda.synchronize()
-            dts = time.perf_counter() - t1
-            flat_sorted = torch.cat([o[:, 0, :] for o in so])
-            inv = torch.empty(len(order), dtype=torch.long)
-            inv[torch.tensor(order)] = torch.arange(len(order))
-            resorted = flat_sorted[inv.to(dev)]
-            # a row that is still running when its batch's width reaches max_len stays all-PAD (reference quirk 1), which
-            # depends on the batch it sits in; every row that finished under both groupings must be token-identical
-            both = (resorted == EOS).any(dim=1) & (preds == EOS).any(dim=1)
-            line["length_sorted_batches"] = {"value": len(pool) / dts, "unit": "reactions/s", "model_calls": gs.model_calls_num,
-                                             "rows_finished_in_both": int(both.sum()),
-                                             "of_those_token_identical": int((resorted[both] == preds[both]).all(dim=1).sum())}
+            dt2 = time.perf_counter() - t1
+            line["batches_as_given_in_flight"] = {"value": len(timed) * a.batch_size / dt2, "unit": "reactions/s",
+                                                  "identical_to_row_scheduled_outputs": all(torch.equal(x, y) for x, y in zip(given, outs)),
+                                                  "model_calls": g2.model_calls_num}
+            line["device_model_calls"] = stats["device"]["model_calls"]
+            line["device_src_tokens_padded"] = stats["device"]["src_tokens_padded"]
         if not a.no_profile:
             # dominant kernel = k_gemm_tn (fp32 MFMA GEMM): HIP events on the launch stream around every launch,
             # same batches, same process, right after the timed region
@@ -248,20 +252,28 @@ def main():
             pg = make_gen(pm)
             import ctypes as C
             gemm_ms, launches, empty_ms = 0.0, 0, 0.0
-            for b in timed:
-                pg.generate(b)
-                ms, n, e = C.c_double(), C.c_int64(), C.c_double()
+            ms, n, e = C.c_double(), C.c_int64(), C.c_double()
+            if rows_sched:
+                # the timed region's workload: the same row groups, one after the other on the profiling session
+                pg.generate_many(timed, in_flight=1, reorder=True, group_size=gen.last_group_size)
                 pm._lib.ttx_last_kernel_profile(pm.session, C.byref(ms), C.byref(n), C.byref(e))
-                gemm_ms += ms.value
-                launches += n.value
-                empty_ms = e.value
+                gemm_ms, launches, empty_ms = ms.value, n.value, e.value
+            else:
+                for b in timed:
+                    pg.generate(b)
+                    pm._lib.ttx_last_kernel_profile(pm.session, C.byref(ms), C.byref(n), C.byref(e))
+                    gemm_ms += ms.value
+                    launches += n.value
+                    empty_ms = e.value
             raw_ms = gemm_ms
             net_ms = max(1e-9, gemm_ms - launches * empty_ms)      # with the cost of an empty event pair removed
             pstats = dict(pg.stats_total)
             pstats["model_calls"] = pg.model_calls_num
-            pw = flops_and_bytes(cfg, pstats, pstats["src_tokens_padded"], len(timed))
+            if rows_sched:
+                pstats = dict(pstats["device"], encode_ms=pstats["encode_ms"], decode_ms=pstats["decode_ms"])
+            pw = flops_and_bytes(cfg, pstats, pstats["src_tokens_padded"], pstats.get("batches", len(timed)))
             ach = pw["gemm_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-            line["roofline"] = {"kernel": "k_gemm3 / k_gemm2 (fp32 v_mfma_f32_32x32x2_f32 GEMMs, every launch of the run)",
+            line["roofline"] = {"kernel": "k_gemm2 (fp32 v_mfma_f32_32x32x2_f32 GEMMs, every launch of the run: encoder, cross K/V, verify steps)",
                                 "bound": "mfma", "achieved": ach,
                                 "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
                                 "traffic": None, "launches": launches, "avg_launch_us": 1e3 * raw_ms / max(1, launches),

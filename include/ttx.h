@@ -237,8 +237,8 @@ int ttx_debug_step_snapshot(ttx_session* s, int32_t* info, float* h_logits, int3
                             int32_t* h_gen);
 
 /* Timing of the dominant kernel for bench.py's roofline: summed HIP-event time (events recorded on the
- * launch stream around every k_gemm_tn launch) and launch count of the most recent generate call on this
- * session; `empty_pair_ms` is what one event pair with no kernel in between measures on the same stream (the
+ * launch stream around every GEMM launch) and launch count of the generate calls on this session since the
+ * previous read (reading resets the sums); `empty_pair_ms` is what one event pair with no kernel in between measures on the same stream (the
  * bracketing overhead contained in every launch's figure).  Only collected when the session was created with
  * TTX_PROFILE_GEMM=1 in the environment (that session launches eagerly, without graphs). */
 int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms);

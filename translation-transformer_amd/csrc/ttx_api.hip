@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <set>
 #include <tuple>
 #include <string>
@@ -294,8 +295,9 @@ struct ttx_session {
   // profiling of the GEMM launches (bench.py roofline)
   bool profile = false;
   bool gemm_v1 = false, attn_v1 = false;
-  int ffn2_split = 8;              // split-K factor of the step's K >= 2048 GEMM (FFN2) on the 32x32 kernel
-  int gemm3_max_n = 768;           // step GEMMs at most this wide use the 32x32 kernel (k_gemm3)
+  int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
+  int proj_split = 1;              // largest split-K factor of the step's d x d projections on the 64x64 kernel
+  int gemm3_max_n = 0;             // step GEMMs at most this wide use the 32x32 kernel (k_gemm3); 0: none
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double prof_ms = 0;
@@ -315,13 +317,31 @@ struct ttx_session {
 
 static thread_local uint64_t* g_alloc_gen = nullptr;   // alloc_generation of the session being sized
 
+// Growing a workspace must not stall the other sessions' streams: hipFree waits for the whole device, so the old
+// allocation is parked here and released at the start of a later top-level call (or when a session is destroyed),
+// when nothing of the previous call is in flight any more.  Work already enqueued keeps using the old allocation;
+// whatever is enqueued after the growth uses the new one (workspaces carry no state across a growth).
+static std::mutex g_retired_mu;
+static std::vector<void*> g_retired;
+
+static void release_retired() {
+  std::vector<void*> v;
+  {
+    std::lock_guard<std::mutex> lk(g_retired_mu);
+    v.swap(g_retired);
+  }
+  if (v.empty()) return;
+  (void)hipDeviceSynchronize();
+  for (void* p : v) (void)hipFree(p);
+}
+
 static int ensure(Buf& b, size_t bytes, hipStream_t st) {
+  (void)st;
   if (bytes <= b.cap) return TTX_OK;
   if (g_alloc_gen) ++*g_alloc_gen;
   if (b.p) {
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipFree(b.p));
+    std::lock_guard<std::mutex> lk(g_retired_mu);
+    g_retired.push_back(b.p);
     b.p = nullptr;
     b.cap = 0;
   }
@@ -352,6 +372,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   s->gemm_v1 = getenv("TTX_GEMM_V1") != nullptr;
   if (const char* g3 = getenv("TTX_GEMM3_MAX_N")) s->gemm3_max_n = atoi(g3);
   if (const char* f2 = getenv("TTX_FFN2_SPLIT")) s->ffn2_split = std::max(1, atoi(f2));
+  if (const char* ps = getenv("TTX_PROJ_SPLIT")) s->proj_split = std::max(1, atoi(ps));
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
@@ -365,6 +386,7 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
   if (s->host_timing && s->host_launches)
     fprintf(stderr, "[ttx host timing] hipGraphLaunch: %lld launches, %.1f us each\n", s->host_launches,
             s->host_launch_us / (double)s->host_launches);
+  release_retired();
   (void)hipDeviceSynchronize();
   for (Buf* b : s->all)
     if (b->p) (void)hipFree(b->p);
@@ -396,7 +418,8 @@ static int choose_splits(const ttx_session* s, bool step, int N, int K) {
   if (!step) return 1;
   if (N <= s->gemm3_max_n && !s->gemm_v1) return (K >= 2048 && K % (256 * s->ffn2_split) == 0) ? s->ffn2_split : 1;   // k_gemm3: K also split over the 4 waves
   int S = 1;                                                                                // k_gemm2: 64-wide tiles of a d-wide output
-  while (S < 8 && K / (S * 2) >= 64 && (K % (S * 2 * 64)) == 0 && cdiv(N, 64) * S < 32) S *= 2;
+  const int cap = K >= 2048 ? s->ffn2_split : s->proj_split;
+  while (S < cap && K / (S * 2) >= 64 && (K % (S * 2 * 64)) == 0 && cdiv(N, 64) * S < 32) S *= 2;
   return S;
 }
 
@@ -1040,8 +1063,8 @@ static int gen_finish_collect(GenJob& j) {
     j.stats->decode_ms = ms;
   }
   if (s->profile) {
-    s->prof_ms = 0;
-    s->prof_launches = (long long)s->ev_used;
+    // summed over the generate calls since the last ttx_last_kernel_profile read
+    s->prof_launches += (long long)s->ev_used;
     for (size_t i = 0; i < s->ev_used; ++i) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) s->prof_ms += ms;
@@ -1118,6 +1141,7 @@ static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, 
                            ttx_gen_stats* stats, void* stream, bool greedy) {
   TTX_TRY(gen_validate(s, d_src, B, Ls, p, d_out, greedy));
   HIP_TRY(hipSetDevice(s->m->device));
+  release_retired();
   // The loop runs on the session's own stream (the caller's may be the legacy null stream, which cannot be
   // captured into a graph); it first waits for the caller's stream, and the call returns only after the
   // session stream has drained, so the outputs are visible to whatever the caller enqueues next.
@@ -1172,6 +1196,7 @@ static int generate_many_impl(ttx_session** sessions, int n_sessions, int n_batc
       if (!d_traj[i] || !d_fin || !d_fin[i]) return fail(TTX_ERR_INVALID, "missing trace buffer for a batch");
   for (int i = 0; i < n_batches; ++i) TTX_TRY(gen_validate(sessions[0], d_src[i], B[i], Ls[i], p, d_out[i], false));
   HIP_TRY(hipSetDevice(sessions[0]->m->device));
+  release_retired();
   hipStream_t caller = (hipStream_t)stream;
   // inputs were produced on the caller's stream: every session stream waits for it once
   hipEvent_t ready;
@@ -1537,6 +1562,8 @@ extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t*
   if (!s) return fail(TTX_ERR_INVALID, "null session");
   if (gemm_ms) *gemm_ms = s->prof_ms;
   if (gemm_launches) *gemm_launches = s->prof_launches;
+  s->prof_ms = 0;
+  s->prof_launches = 0;
   if (empty_pair_ms) *empty_pair_ms = s->prof_empty_pair_ms < 0 ? 0.0 : s->prof_empty_pair_ms;
   return TTX_OK;
 }

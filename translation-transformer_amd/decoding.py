@@ -128,7 +128,10 @@ class TranslationInferenceGreedySpeculative:
         srcs = [b.to(m.device, torch.int64) for b in batches]
         sizes = [int(s.shape[0]) for s in srcs]
         R = sum(sizes)
-        gsz = int(group_size or max(sizes))
+        # device group size: the given batch size is not binding any more; larger groups run the GEMMs at better MFMA
+        # occupancy, but at least `in_flight` groups should exist so that tails overlap
+        gsz = int(group_size or min(256, max(max(sizes), -(-R // max(1, in_flight)))))
+        self.last_group_size = gsz
         # all rows in one right-padded matrix; a row's length is the position after its last non-PAD token
         Lmax = max(int(s.shape[1]) for s in srcs)
         allsrc = torch.full((R, Lmax), self.pad_token, dtype=torch.int64, device=m.device)
@@ -187,8 +190,16 @@ class TranslationInferenceGreedySpeculative:
         for st in stats:
             t["encode_ms"] += st.encode_ms
             t["decode_ms"] += st.decode_ms
-        t["device_model_calls"] = t.get("device_model_calls", 0) + sum(int(st.model_calls) for st in stats)
-        t["device_src_tokens_padded"] = t.get("device_src_tokens_padded", 0) + sum(int(s.numel()) for s in gsrc)
+        # what the device actually executed (row groups), beside the reference-equivalent per-batch counters above
+        dv = t.setdefault("device", {"model_calls": 0, "accepted_tokens": 0, "produced_tokens": 0, "verified_positions": 0,
+                                     "kv_prefix_positions": 0, "src_positions": 0, "src_tokens_padded": 0, "batches": 0})
+        for st, gs in zip(stats, gsrc):
+            for k in ("model_calls", "accepted_tokens", "produced_tokens", "verified_positions", "kv_prefix_positions",
+                      "src_positions"):
+                dv[k] += int(getattr(st, k))
+            dv["src_tokens_padded"] += int(gs.numel())
+            dv["batches"] += 1
+        t["device_model_calls"] = dv["model_calls"]
         if failed is not None:
             raise N.ReferenceError_(f"batch {failed}: a row finished at a width beyond max_len: shape mismatch in the reference "
                                     "(speculative_decoding.py:158)")

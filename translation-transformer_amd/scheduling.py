@@ -37,38 +37,34 @@ class BatchReplay:
 
 def replay_batch(traj: np.ndarray, fin_step: np.ndarray, max_len: int, draft_len: int, n_drafts: int = 1) -> BatchReplay:
     """traj: int [B, max_len + 1], traj[r, t] = front of row r after its t-th verify step (column 0 is 0, -1
-    past the row's last step); fin_step: int [B], step at which row r produced EOS (0: it never did)."""
+    past the row's last step); fin_step: int [B], step at which row r produced EOS (0: it never did).
+
+    The reference's loop, all iterations at once: row r takes part in iteration t while it has not finished
+    (fin_step[r] == 0 or >= t); the width after iteration t is max(front before t over those rows) + draft_len + 2;
+    iteration t happens iff every earlier one did, somebody is still running and the width before it is < max_len."""
     traj = np.asarray(traj).astype(np.int64)
-    fin_step = np.asarray(fin_step).astype(np.int64)
-    B = traj.shape[0]
-    running = np.ones(B, dtype=bool)
-    finished = np.zeros(B, dtype=bool)
-    width, t = 1, 0
-    calls = acc = prod = ver = prefix = rows_it = 0
-    error = False
+    fin = np.asarray(fin_step).astype(np.int64)
+    B, T = traj.shape[0], traj.shape[1] - 1
+    t = np.arange(1, T + 1)
+    takes_part = (fin == 0)[:, None] | (fin[:, None] >= t[None, :])          # [B, T]
+    before, after = traj[:, :-1], traj[:, 1:]
+    width = np.where(takes_part, before, -1).max(axis=0) + draft_len + 2     # after iteration t (:97-102, :145)
+    width_before = np.concatenate([[1], width[:-1]])
+    happens = np.logical_and.accumulate(takes_part.any(axis=0) & (width_before < max_len))   # :93
+    finishing = (fin[:, None] == t[None, :]).any(axis=0)
+    raises = happens & finishing & (width > max_len)                         # :158 — shape mismatch in the reference
+    error = bool(raises.any())
+    if error:
+        happens = happens & (t <= t[np.argmax(raises)])                      # the loop dies inside that iteration
+    n_it = int(happens.sum())
+    m = takes_part & happens[None, :]
+    if ((before < 0) | (after < 0))[m].any():
+        raise ValueError("row trace shorter than the batch needs: traces were not produced under the per-row rule")
+    finished = (fin >= 1) & (fin <= n_it) & (not error)
+    rows_it = int(m.sum())
+    adv = int((after - before)[m].sum())
     rps = 1 + n_drafts * draft_len
-    while width < max_len and running.any():                       # :93
-        t += 1
-        before = traj[running, t - 1]
-        after = traj[running, t]
-        if (before < 0).any() or (after < 0).any():
-            raise ValueError("row trace shorter than the batch needs: traces were not produced under the per-row rule")
-        width = int(before.max()) + draft_len + 2                  # :97-102, :145
-        calls += 1
-        n_run = int(running.sum())
-        rows_it += n_run
-        acc += int((after - before - 1).sum())
-        prod += int((after - before).sum())
-        ver += n_run * rps
-        prefix += int(before.sum())
-        done = running & (fin_step == t)
-        if done.any():
-            if width > max_len:                                    # :158 — shape mismatch in the reference
-                error = True
-                break
-            finished |= done
-            running &= ~done
-    return BatchReplay(calls, error, finished, acc, prod, ver, prefix, rows_it)
+    return BatchReplay(n_it, error, finished, adv - rows_it, adv, rows_it * rps, int(before[m].sum()), rows_it)
 
 
 def plan_row_groups(lengths, group_size: int):
