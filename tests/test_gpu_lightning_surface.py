@@ -87,3 +87,29 @@ def test_predict_surface(tmp_path, generation, capsys):
     if generation == "beam_search_speculative":
         keys |= {"accepted_tokens", "acceptance_rate"}
     assert set(rep) == keys and rep["algorithm"] == generation and rep["model_calls"] > 0
+
+
+def test_predict_rows_schedule_equals_per_batch(tmp_path):
+    """run_predict(schedule="rows"): same CSV, same report counters as the per-batch loop."""
+    import translation_transformer_amd as tta
+    st, cfg = tiny_state()
+    tkz = FixtureTokenizer()
+    src, tgt, _, _ = fixture_tokens()
+    batches = [{"src_tokens": src[i:j].cuda(), "tgt_tokens": tgt[i:j].cuda()} for i, j in ((0, 3), (3, 4), (4, 8), (8, 10))]
+    results = {}
+    for schedule in ("batches", "rows"):
+        report_file = tmp_path / f"r_{schedule}.txt"
+        mod = tta.VanillaEncoderDecoderTransformerLightning(
+            src_tokenizer=tkz, tgt_tokenizer=tkz, embedding_dim=cfg["embedding_dim"], feedforward_dim=cfg["feedforward_dim"],
+            num_encoder_layers=cfg["num_encoder_layers"], num_decoder_layers=cfg["num_decoder_layers"],
+            num_heads=cfg["num_heads"], share_embeddings=True, generation="greedy_speculative", max_len=150, n_drafts=3,
+            draft_len=10, report_prediction_file=str(report_file))
+        mod.load_state_dict({"model." + k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+        out_csv = tmp_path / f"pred_{schedule}.csv"
+        outs = tta.run_predict(mod, batches, writer=CsvWriter(out_csv), schedule=schedule, window=3, in_flight=2)
+        rep = json.loads(report_file.read_text().strip().split("\n")[-1])
+        results[schedule] = (out_csv.read_text(), rep["model_calls"], outs)
+    assert results["rows"][0] == results["batches"][0]
+    assert results["rows"][1] == results["batches"][1]
+    for a, b in zip(results["rows"][2], results["batches"][2]):
+        assert torch.equal(a, b)

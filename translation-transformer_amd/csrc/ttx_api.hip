@@ -297,7 +297,7 @@ struct ttx_session {
   bool gemm_v1 = false, attn_v1 = false;
   int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
   int proj_split = 1;              // largest split-K factor of the step's d x d projections on the 64x64 kernel
-  int gemm3_max_n = 0;             // step GEMMs at most this wide use the 32x32 kernel (k_gemm3); 0: none (see DESIGN.md §4.4)
+  int gemm3_max_n = 0;             // step GEMMs at most this wide use the 32x32 kernel (k_gemm3); 0: none (see DESIGN.md §4.2)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double prof_ms = 0;

@@ -129,7 +129,7 @@ class TranslationInferenceGreedySpeculative:
         sizes = [int(s.shape[0]) for s in srcs]
         R = sum(sizes)
         # device group size: the given batch size is not binding any more; larger groups run the GEMMs at better MFMA
-        # occupancy (DESIGN.md §4.4), but at least `in_flight` groups should exist so that tails overlap
+        # occupancy (DESIGN.md §4.2), but at least `in_flight` groups should exist so that tails overlap
         gsz = int(group_size or min(256, max(max(sizes), -(-R // max(1, in_flight)))))
         self.last_group_size = gsz
         # all rows in one right-padded matrix; a row's length is the position after its last non-PAD token

@@ -180,17 +180,46 @@ class VanillaEncoderDecoderTransformerLightning(LightningModule):
     validation_step = test_step = training_step
 
 
-def run_predict(module: VanillaEncoderDecoderTransformerLightning, batches, writer=None, datamodule=None) -> list:
+def run_predict(module: VanillaEncoderDecoderTransformerLightning, batches, writer=None, datamodule=None,
+                schedule: str = "batches", window: int = 256, in_flight: int = 8) -> list:
     """Stand-in for ``Trainer.predict`` when pytorch_lightning is absent: same hook order
-    (on_predict_start -> predict_step per batch -> writer.write_on_batch_end -> on_predict_end)."""
+    (on_predict_start -> predict_step per batch -> writer.write_on_batch_end -> on_predict_end).
+
+    ``schedule="rows"`` (greedy_speculative only) takes `window` batches at a time, decodes their rows in
+    length-sorted device groups (generate_many(reorder=True): outputs and model_calls per given batch are those of
+    predict_step) and then hands the batches to the writer in their original order.  The only observable difference
+    to the per-batch loop: if the reference would raise on some batch, the error surfaces before the batches of
+    that window have been written instead of after the preceding ones."""
+    if schedule not in ("batches", "rows"):
+        raise ValueError("schedule must be 'batches' or 'rows'")
     module.trainer = SimpleNamespace(datamodule=datamodule)
     outs = []
     with torch.inference_mode():
         module.on_predict_start()
-        for i, batch in enumerate(batches):
-            pred = module.predict_step(batch, i)
-            if writer is not None:
-                writer.write_on_batch_end(module.trainer, module, pred, None, batch, i, 0)
-            outs.append(pred)
+        if schedule == "rows" and hasattr(module.generator, "generate_many"):
+            pending = []
+
+            def flush(first_idx):
+                preds = module.generator.generate_many([b["src_tokens"] for b in pending], in_flight=in_flight, reorder=True)
+                for k, (b, pred) in enumerate(zip(pending, preds)):
+                    if writer is not None:
+                        writer.write_on_batch_end(module.trainer, module, pred, None, b, first_idx + k, 0)
+                    outs.append(pred)
+                pending.clear()
+
+            first = 0
+            for i, batch in enumerate(batches):
+                pending.append(batch)
+                if len(pending) == window:
+                    flush(first)
+                    first = i + 1
+            if pending:
+                flush(first)
+        else:
+            for i, batch in enumerate(batches):
+                pred = module.predict_step(batch, i)
+                if writer is not None:
+                    writer.write_on_batch_end(module.trainer, module, pred, None, batch, i, 0)
+                outs.append(pred)
         module.on_predict_end()
     return outs
