@@ -243,6 +243,12 @@ int ttx_debug_step_snapshot(ttx_session* s, int32_t* info, float* h_logits, int3
  * TTX_PROFILE_GEMM=1 in the environment (that session launches eagerly, without graphs). */
 int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms);
 
+/* Development aid (tools/bench_gemm.py): times one GEMM shape in isolation on random operands.  variant 2 / 3 / 4 =
+ * the 64x64, 32x32 and 128x128 kernels; splits 0 = fused bias epilogue, > 0 = split-K slabs.  Returns microseconds
+ * per launch over `reps` back-to-back launches and the largest absolute difference to the 64x64 kernel's result. */
+int ttx_debug_gemm_bench(ttx_session* s, int M, int N, int K, int splits, int variant, int reps, double* us_per_launch,
+                         double* max_abs_diff);
+
 #ifdef __cplusplus
 }
 #endif

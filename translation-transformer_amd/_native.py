@@ -90,6 +90,7 @@ SYMBOLS = {
     "ttx_tokenizer_encode_batch": (C.c_int, [_VP, C.POINTER(C.c_char_p), _I, _VP, _I]),
     "ttx_tokenizer_decode": (C.c_int, [_VP, _VP, _I, _VP, _I]),
     "ttx_debug_step_snapshot": (C.c_int, [_VP, C.POINTER(C.c_int32), _VP, _VP, _VP, _VP]),
+    "ttx_debug_gemm_bench": (C.c_int, [_VP, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ttx_last_kernel_profile": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 
@@ -116,6 +117,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}",
            "-o", str(LIB_PATH), str(CSRC / "ttx_api.hip")]
+    cmd[3:3] = os.environ.get("TTX_HIPCC_FLAGS", "").split()      # experiments: extra -D switches
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -296,6 +296,7 @@ struct ttx_session {
   bool profile = false;
   bool gemm_v1 = false, attn_v1 = false;
   int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
+  int big_min_tiles = 192;         // 128x128 tiling once it yields this many workgroups (k_gemm24); 0: never
   int proj_split = 1;              // largest split-K factor of the step's d x d projections on the 64x64 kernel
   int gemm3_max_n = 0;             // step GEMMs at most this wide use the 32x32 kernel (k_gemm3); 0: none
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -373,6 +374,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   if (const char* g3 = getenv("TTX_GEMM3_MAX_N")) s->gemm3_max_n = atoi(g3);
   if (const char* f2 = getenv("TTX_FFN2_SPLIT")) s->ffn2_split = std::max(1, atoi(f2));
   if (const char* ps = getenv("TTX_PROJ_SPLIT")) s->proj_split = std::max(1, atoi(ps));
+  if (const char* bt = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(bt));
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
@@ -435,6 +437,7 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
   a.k_per_split = K / S;
   a.slab_stride = slab_stride;
   a.dbg = nullptr;
+  a.big_min_tiles = 0;
   if (s->gemm_debug && s->dbg_gemm.p && (size_t)cdiv(N, 64) * cdiv(Mmax, 64) * S * 64 <= s->dbg_gemm.cap && N == s->gemm_debug_n && !a.raw)
     a.dbg = s->dbg_gemm.as<unsigned long long>();
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -461,6 +464,13 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
       case 128: hipLaunchKernelGGL((k_gemm3<128>), grid, dim3(256), 0, st, a); break;
       default: hipLaunchKernelGGL((k_gemm3<0>), grid, dim3(256), 0, st, a); break;
     }
+  } else if (a.k_per_split % 256 == 0 && !s->gemm_v1 && s->big_min_tiles > 0 &&
+             (long long)cdiv(Mmax, 128) * cdiv(N, 128) * S >= s->big_min_tiles) {
+    // enough rows (at most) for the 128x128 tiling: one launch that picks the tiling from the live row count
+    a.big_min_tiles = s->big_min_tiles;
+    dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
+    if (a.k_per_split == 256) hipLaunchKernelGGL((k_gemm24<4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm24<0>), grid, dim3(256), 0, st, a);
   } else if ((a.k_per_split == 64 || a.k_per_split == 128 || a.k_per_split % 256 == 0) && !s->gemm_v1) {
     dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
     switch (a.k_per_split) {
@@ -1556,6 +1566,123 @@ extern "C" int ttx_tokenizer_decode(const ttx_tokenizer* t, const int64_t* ids, 
   }
   if (out && cap > 0) out[std::min(len, (size_t)cap - 1)] = '\0';
   return (int)len;
+}
+
+// Development aid (tools/bench_gemm.py): one GEMM shape in isolation.  variant 2 = k_gemm2, 3 = k_gemm3, 4 = k_gemm4;
+// `splits` as in launch_gemm (0: bias/relu epilogue, >0: raw slabs).  Reports microseconds per launch over `reps`
+// back-to-back launches and the largest absolute difference of the (slab-summed) result to k_gemm2's.
+extern "C" int ttx_debug_gemm_bench(ttx_session* s, int M, int N, int K, int splits, int variant, int reps, double* us_per_launch,
+                                    double* max_abs_diff) {
+  if (!s || M <= 0 || N <= 0 || K <= 0 || K % 64 || reps <= 0) return fail(TTX_ERR_INVALID, "bad argument to ttx_debug_gemm_bench");
+  HIP_TRY(hipSetDevice(s->m->device));
+  const int S = splits > 0 ? splits : 1;
+  if (K % S || (K / S) % 64) return fail(TTX_ERR_INVALID, "K / splits must be a multiple of 64");
+  std::vector<float> hx((size_t)M * K), hw((size_t)N * K), hb(N);
+  uint64_t z = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { z ^= z << 13; z ^= z >> 7; z ^= z << 17; return (float)((z >> 40) & 0xffff) / 65536.f - 0.5f; };
+  for (auto& v : hx) v = rnd();
+  for (auto& v : hw) v = rnd() * 0.125f;
+  for (auto& v : hb) v = rnd();
+  float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dref = nullptr;
+  int* dm = nullptr;
+  HIP_TRY(hipMalloc(&dx, hx.size() * 4));
+  HIP_TRY(hipMalloc(&dw, hw.size() * 4));
+  HIP_TRY(hipMalloc(&db, hb.size() * 4));
+  HIP_TRY(hipMalloc(&dy, (size_t)S * M * N * 4));
+  HIP_TRY(hipMalloc(&dref, (size_t)S * M * N * 4));
+  HIP_TRY(hipMalloc(&dm, 4));
+  HIP_TRY(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dm, &M, 4, hipMemcpyHostToDevice));
+  GemmArgs a;
+  a.X = dx; a.ldx = K; a.W = dw; a.ldw = K; a.bias = db; a.Y = dy; a.ldy = N; a.m_ptr = dm; a.M = M; a.N = N; a.K = K;
+  a.relu = 0; a.raw = splits > 0 ? 1 : 0; a.k_per_split = K / S; a.slab_stride = (long long)M * N; a.dbg = nullptr;
+  a.big_min_tiles = s->big_min_tiles;
+  if (variant == 24 && (K / S) % 256) return fail(TTX_ERR_INVALID, "variant 24 needs K / splits to be a multiple of 256");
+  hipStream_t st = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  auto launch = [&](int var, const GemmArgs& g) {
+    if (var == 24) {
+      dim3 grid(cdiv(N, 64), cdiv(M, 64), S);
+      if (g.k_per_split == 256) hipLaunchKernelGGL((k_gemm24<4>), grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((k_gemm24<0>), grid, dim3(256), 0, st, g);
+    } else if (var == 4) {
+      hipLaunchKernelGGL(k_gemm4, dim3(cdiv(N, 128), cdiv(M, 128), S), dim3(256), 0, st, g);
+    } else if (var == 3) {
+      dim3 grid(cdiv(N, 32), cdiv(M, 32), S);
+      switch (g.k_per_split / 4) {
+        case 16: hipLaunchKernelGGL((k_gemm3<16>), grid, dim3(256), 0, st, g); break;
+        case 64: hipLaunchKernelGGL((k_gemm3<64>), grid, dim3(256), 0, st, g); break;
+        case 128: hipLaunchKernelGGL((k_gemm3<128>), grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL((k_gemm3<0>), grid, dim3(256), 0, st, g); break;
+      }
+    } else {
+      dim3 grid(cdiv(N, 64), cdiv(M, 64), S);
+      switch (g.k_per_split) {
+        case 64: hipLaunchKernelGGL((k_gemm2<1>), grid, dim3(256), 0, st, g); break;
+        case 128: hipLaunchKernelGGL((k_gemm2<2>), grid, dim3(256), 0, st, g); break;
+        case 256: hipLaunchKernelGGL((k_gemm2<4>), grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL((k_gemm2<0>), grid, dim3(256), 0, st, g); break;
+      }
+    }
+  };
+  GemmArgs ref = a;
+  ref.Y = dref;
+  launch(2, ref);
+  unsigned long long* ddbg = nullptr;
+  const size_t n_wg4 = (size_t)cdiv(N, 128) * cdiv(M, 128) * S;
+  if (variant == 14) {       // k_gemm4 with per-workgroup phase stamps of its second tile pair
+    HIP_TRY(hipMalloc(&ddbg, n_wg4 * 64));
+    HIP_TRY(hipMemset(ddbg, 0, n_wg4 * 64));
+    a.dbg = ddbg;
+    variant = 4;
+  }
+  for (int i = 0; i < 3; ++i) launch(variant, a);
+  HIP_TRY(hipGetLastError());
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) launch(variant, a);
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (us_per_launch) *us_per_launch = 1e3 * ms / reps;
+  if (max_abs_diff) {
+    std::vector<float> y((size_t)S * M * N), yr((size_t)S * M * N);
+    HIP_TRY(hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(yr.data(), dref, yr.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (size_t i = 0; i < (size_t)M * N; ++i) {
+      double u = 0, v = 0;
+      for (int k = 0; k < S; ++k) { u += y[(size_t)k * M * N + i]; v += yr[(size_t)k * M * N + i]; }
+      worst = std::max(worst, std::fabs(u - v));
+    }
+    *max_abs_diff = worst;
+  }
+  if (ddbg) {
+    std::vector<unsigned long long> h(n_wg4 * 8);
+    HIP_TRY(hipMemcpy(h.data(), ddbg, h.size() * 8, hipMemcpyDeviceToHost));
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    size_t n = 0;
+    for (size_t w = 0; w < n_wg4; ++w) {
+      const unsigned long long* q = &h[w * 8];
+      if (!q[0] || !q[7]) continue;
+      for (int k = 0; k < 7; ++k) acc[k] += (double)(q[k + 1] - q[k]);
+      ++n;
+    }
+    if (n)
+      fprintf(stderr, "[ttx gemm4 stamps] %zu workgroups, shader cycles: lds-write(f0) %.0f | issue loads %.0f | barrier %.0f | mma(0) %.0f | "
+                      "write+loads(f1) %.0f | barrier %.0f | mma(1) %.0f\n", n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n,
+              acc[5] / n, acc[6] / n);
+    (void)hipFree(ddbg);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(st);
+  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dref); (void)hipFree(dm);
+  return TTX_OK;
 }
 
 extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms) {

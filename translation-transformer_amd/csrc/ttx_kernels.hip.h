@@ -55,6 +55,7 @@ struct GemmArgs {
   int raw;                   // 1: write un-biased partial sums to slab blockIdx.z
   long long slab_stride;     // floats between slabs
   unsigned long long* dbg;   // diagnostic builds only: per-workgroup phase stamps (100 MHz realtime clock)
+  int big_min_tiles;         // k_gemm24: smallest 128x128-tile count (x splits) at which that tiling is used
 };
 
 template <int WGM, int WGN>
@@ -200,20 +201,22 @@ __device__ __forceinline__ void g2_mma(f32x16& acc, const float* ap, const float
 
 // NT = number of 64-deep K tiles per workgroup when it is 1, 2 or 4 (straight-line code, every tile
 // requested up front); NT = 0: any multiple of 4 tiles, ring slots refilled as they drain.
-template <int NT>
-__global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
-  constexpr int BM = 64, BN = 64, BK = 64, LDT = BK + 4, RING = 4;
-  __shared__ __attribute__((aligned(16))) float As[TTX_G2_BUFS][BM * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[TTX_G2_BUFS][BN * LDT];
+constexpr int G24_SMEM_FLOATS = 2 * 2 * 128 * 36;      // 73 728 B: the larger of the two tilings' LDS images
 
-  unsigned long long* dbg = a.dbg ? a.dbg + 8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
+template <int NT>
+__device__ __forceinline__ void g2_body(const GemmArgs& a, const int M, const int bx, const int by, const int bz, float* smem) {
+  constexpr int BM = 64, BN = 64, BK = 64, LDT = BK + 4, RING = 4;
+  typedef float (*TileBufs)[BM * LDT];
+  TileBufs As = reinterpret_cast<TileBufs>(smem);
+  TileBufs Bs = reinterpret_cast<TileBufs>(smem + TTX_G2_BUFS * BM * LDT);
+
+  unsigned long long* dbg = a.dbg ? a.dbg + 8 * (size_t)(bx + gridDim.x * (by + gridDim.y * bz)) : nullptr;
 #define TTX_GSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
   TTX_GSTAMP(0);
-  const int M = a.m_ptr ? *a.m_ptr : a.M;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   if (m0 >= M) return;
   TTX_GSTAMP(1);
-  const int kbeg = blockIdx.z * a.k_per_split;
+  const int kbeg = bz * a.k_per_split;
   const int kend = min(a.K, kbeg + a.k_per_split);
   const int ntiles = (kend - kbeg) / BK;
 
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
   }
 
   TTX_GSTAMP(3);
-  float* Y = a.Y + (a.raw ? (size_t)blockIdx.z * a.slab_stride : 0);
+  float* Y = a.Y + (a.raw ? (size_t)bz * a.slab_stride : 0);
   const int col = n0 + wn * 32 + r;
   // all values are finished before the first (predicated) store: a pending load inside the store
   // branches would make the compiler drain vmcnt — and with it the previous store — sixteen times
@@ -304,7 +307,11 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
   float val[16];
 #pragma unroll
   for (int v = 0; v < 16; ++v) val[v] = fmaxf(acc[v] + bv, lo);
-  if (col < a.N) {
+  if (m0 + BM <= M && n0 + BN <= a.N) {             // interior workgroup (uniform): straight-line stores
+    float* yp = Y + (size_t)(m0 + wm * 32 + 4 * h) * a.ldy + col;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) yp[(size_t)((v & 3) + 8 * (v >> 2)) * a.ldy] = val[v];
+  } else if (col < a.N) {
     float* yp = Y + (size_t)(m0 + wm * 32 + 4 * h) * a.ldy + col;
     const int rows_left = M - (m0 + wm * 32 + 4 * h);
 #pragma unroll
@@ -315,6 +322,226 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
   }
   if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TTX_GSTAMP(4); }
 #undef TTX_GSTAMP
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * TTX_G2_BUFS * 64 * 68];
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  g2_body<NT>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM v4 for launches with thousands of rows (row schedule: M up to ~8 000 step rows; encoder / cross-K/V bulk
+// passes): 128x128 output tile per workgroup, 2x2 waves of 64x64 (four independent 32x32 fp32-MFMA accumulators
+// per wave, so back-to-back MFMAs never wait on each other), 32-deep K tiles, LDS double buffer (stride 36 floats:
+// conflict-free ds_read_b128), one barrier per tile.  Against the 64x64 kernel: half the L2->LDS bytes and half the
+// LDS->register bytes per MFMA, 4 096 MFMA cycles per wave between barriers instead of 2 048.  The next tile's
+// global loads are issued before the MFMA block of the current one and written to the other LDS buffer after the
+// following barrier (loads are unconditional, tile index clamped: counted vmcnt waits).
+struct G4Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
+
+__device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const int bx, const int by, const int bz, float* smem) {
+  constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
+  typedef float (*TileBufs)[BM * LDT];
+  TileBufs As = reinterpret_cast<TileBufs>(smem);
+  TileBufs Bs = reinterpret_cast<TileBufs>(smem + 2 * BM * LDT);
+  unsigned long long* dbg = a.dbg ? a.dbg + 8 * (size_t)(bx + gridDim.x * (by + gridDim.y * bz)) : nullptr;
+#ifdef TTX_G4_STAMP_OUTER
+  if (dbg && threadIdx.x == 0) dbg[0] = clock64();
+#endif
+  const int m0 = by * BM, n0 = bx * BN;
+  if (m0 >= M) return;
+  const int kbeg = bz * a.k_per_split;
+  const int kend = min(a.K, kbeg + a.k_per_split);
+  const int ntiles = (kend - kbeg) / BK;
+  const int t = threadIdx.x;
+  const int lr = t >> 3, lc = (t & 7) * 4;       // 8 float4 per 32-float row, 32 rows per pass, 4 passes
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const float* xp[4];
+  const float* wp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xp[i] = a.X + (size_t)min(m0 + lr + 32 * i, M - 1) * a.ldx + kbeg + lc;
+    wp[i] = a.W + (size_t)min(n0 + lr + 32 * i, a.N - 1) * a.ldw + kbeg + lc;
+  }
+  auto gload = [&](int tile) {
+    G4Frag f;
+    const int ko = tile * BK;
+    f.a0 = *reinterpret_cast<const float4*>(xp[0] + ko);
+    f.a1 = *reinterpret_cast<const float4*>(xp[1] + ko);
+    f.a2 = *reinterpret_cast<const float4*>(xp[2] + ko);
+    f.a3 = *reinterpret_cast<const float4*>(xp[3] + ko);
+    f.b0 = *reinterpret_cast<const float4*>(wp[0] + ko);
+    f.b1 = *reinterpret_cast<const float4*>(wp[1] + ko);
+    f.b2 = *reinterpret_cast<const float4*>(wp[2] + ko);
+    f.b3 = *reinterpret_cast<const float4*>(wp[3] + ko);
+    return f;
+  };
+  auto lstore = [&](const G4Frag& f, int buf) {
+    float* as = As[buf] + lr * LDT + lc;
+    float* bs = Bs[buf] + lr * LDT + lc;
+    *reinterpret_cast<float4*>(as) = f.a0;
+    *reinterpret_cast<float4*>(as + 32 * LDT) = f.a1;
+    *reinterpret_cast<float4*>(as + 64 * LDT) = f.a2;
+    *reinterpret_cast<float4*>(as + 96 * LDT) = f.a3;
+    *reinterpret_cast<float4*>(bs) = f.b0;
+    *reinterpret_cast<float4*>(bs + 32 * LDT) = f.b1;
+    *reinterpret_cast<float4*>(bs + 64 * LDT) = f.b2;
+    *reinterpret_cast<float4*>(bs + 96 * LDT) = f.b3;
+  };
+
+  f32x16 c00, c01, c10, c11;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; }
+  const int aoff = (wm * 64 + r) * LDT + 4 * h, boff = (wn * 64 + r) * LDT + 4 * h;
+#ifdef TTX_G4_PRIO
+  // Two workgroups share a CU (one wave of each per SIMD).  With equal priority the SIMD alternates between their
+  // MFMAs, both advance in lockstep and reach their LDS/barrier phases together, leaving the MFMA pipe idle then.
+  // Giving the workgroup whose first wave sits in an odd wave slot a higher priority makes the phases complementary.
+  __shared__ int s_prio;
+  if (t == 0) s_prio = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1;     // HW_ID.WAVE_ID
+  __syncthreads();
+  if (s_prio) __builtin_amdgcn_s_setprio(3);
+#endif
+
+  auto mma = [&](int buf) {
+    const float* ap = As[buf] + aoff;
+    const float* bp = Bs[buf] + boff;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ap + kk);
+      const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDT + kk);
+      const float4 b0 = *reinterpret_cast<const float4*>(bp + kk);
+      const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDT + kk);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, c11, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, c11, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, c11, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, c11, 0, 0, 0);
+    }
+  };
+  // two register tiles in flight (static slots, clamped refills: same shape as k_gemm2's ring): a tile's loads are
+  // issued two MFMA blocks (~3.4 us) before its LDS write.  The K range is a multiple of 64: ntiles is even.
+  const int last = ntiles - 1;
+  const int bcol = n0 + wn * 64 + r;
+  const float bias0 = (!a.raw && a.bias) ? a.bias[min(bcol, a.N - 1)] : 0.f;
+  const float bias1 = (!a.raw && a.bias) ? a.bias[min(bcol + 32, a.N - 1)] : 0.f;
+  asm volatile("" ::: "memory");
+  G4Frag f0 = gload(0);
+  asm volatile("" ::: "memory");        // issue order f0 then f1 also ahead of the loop: the header waits with vmcnt(8), not 0
+  G4Frag f1 = gload(1);
+#ifdef TTX_G4_STAMP_OUTER
+#define TTX_G4STAMP(k) do { } while (0)
+#define TTX_G4OUTER(k) do { if (dbg && t == 0) dbg[k] = clock64(); } while (0)
+#else
+#define TTX_G4STAMP(k) do { if (dbg && i == 2 && t == 0) dbg[k] = clock64(); } while (0)
+#define TTX_G4OUTER(k) do { } while (0)
+#endif
+  TTX_G4OUTER(1);
+  for (int i = 0; i < ntiles; i += 2) {
+    TTX_G4STAMP(0);
+    lstore(f0, 0);
+    if (i == 0) TTX_G4OUTER(2);
+    asm volatile("" ::: "memory");      // LDS writes first, then the refill into the same registers (no copies, counted vmcnt)
+    TTX_G4STAMP(1);
+    f0 = gload(min(i + 2, last));
+    TTX_G4STAMP(2);
+    __syncthreads();
+    TTX_G4STAMP(3);
+    mma(0);
+    TTX_G4STAMP(4);
+    lstore(f1, 1);
+    asm volatile("" ::: "memory");
+    f1 = gload(min(i + 3, last));
+    TTX_G4STAMP(5);
+    __syncthreads();
+    TTX_G4STAMP(6);
+    mma(1);
+    TTX_G4STAMP(7);
+  }
+  TTX_G4OUTER(3);
+#undef TTX_G4STAMP
+
+  // Epilogue.  The bias values were requested before the K loop (a load still pending here would make every
+  // predicated store below wait for vmcnt(0), i.e. for the previous store: 64 serialised round trips).
+  float* Y = a.Y + (a.raw ? (size_t)bz * a.slab_stride : 0);
+  const float lo = a.relu ? 0.f : -INFINITY;
+  auto store_tile = [&](const f32x16& c, int tm, int tn, float bv) {
+    const int col = n0 + wn * 64 + tn * 32 + r;
+    float val[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) val[v] = fmaxf(c[v] + bv, lo);
+    const int row0 = m0 + wm * 64 + tm * 32 + 4 * h;
+    float* yp = Y + (size_t)row0 * a.ldy + col;
+    if (m0 + BM <= M && n0 + BN <= a.N) {            // interior workgroup (uniform): straight-line stores
+#pragma unroll
+      for (int v = 0; v < 16; ++v) yp[(size_t)((v & 3) + 8 * (v >> 2)) * a.ldy] = val[v];
+    } else if (col < a.N) {
+      const int rows_left = M - row0;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int dr = (v & 3) + 8 * (v >> 2);
+        if (dr < rows_left) yp[(size_t)dr * a.ldy] = val[v];
+      }
+    }
+  };
+  store_tile(c00, 0, 0, bias0);
+  store_tile(c01, 0, 1, bias1);
+  store_tile(c10, 1, 0, bias0);
+  store_tile(c11, 1, 1, bias1);
+#ifdef TTX_G4_STAMP_OUTER
+  if (dbg && t == 0) {
+    dbg[4] = clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dbg[5] = clock64(); dbg[6] = dbg[5]; dbg[7] = dbg[5];
+  }
+#endif
+#undef TTX_G4OUTER
+}
+
+__global__ __launch_bounds__(256) void k_gemm4(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[G24_SMEM_FLOATS];
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  g4_body(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// One launch, two tilings: the grid is laid out for 64x64 tiles; when the row count read from the device gives the
+// 128x128 tiling at least `big_min_tiles` workgroups (GemmArgs), the first workgroups in dispatch order each compute
+// a 128x128 tile and the others leave at once, otherwise all compute their 64x64 tile.  Both tilings accumulate a
+// K range in the same order in one accumulator per output element: the results are bit-identical, so the choice may
+// follow the live row count without touching batch invariance.
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm24(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[G24_SMEM_FLOATS];
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  const int big_tiles = ((M + 127) >> 7) * ((a.N + 127) >> 7) * (int)gridDim.z;
+  if (big_tiles >= a.big_min_tiles) {
+    // The first big_tiles workgroups of the whole grid in dispatch order take the tiles (all K slices included): the
+    // dispatcher hands consecutive workgroups to consecutive CUs, so a contiguous block spreads one per CU / XCD;
+    // actives separated by idle workgroups ended up two to a CU with other CUs empty (2x the time, measured).
+    const int nbx = (a.N + 127) >> 7, nby = (M + 127) >> 7;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin >= big_tiles) return;
+    const int slice = lin / (nbx * nby), rem = lin - slice * (nbx * nby);
+    g4_body(a, M, rem % nbx, rem / nbx, slice, smem);
+  } else {
+    g2_body<NT>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
