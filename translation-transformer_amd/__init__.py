@@ -8,3 +8,4 @@ from .decoding import (TranslationInferenceGreedySpeculative, TranslationInferen
 from .lightning_model import VanillaEncoderDecoderTransformerLightning, run_predict  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
 from .tokenizer import NativeSmilesTokenizer  # noqa: F401,E402
+from . import scheduling, scoring  # noqa: F401,E402
