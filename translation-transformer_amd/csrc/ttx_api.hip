@@ -294,7 +294,7 @@ struct ttx_session {
   size_t attn_lds_limit = 0;
   // profiling of the GEMM launches (bench.py roofline)
   bool profile = false;
-  bool gemm_v1 = false, attn_v1 = false;
+  bool gemm_v1 = false, attn_v1 = false, attn_v3 = true;
   int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
   int big_min_tiles = 192;         // 128x128 tiling once it yields this many workgroups (k_gemm24); 0: never
   int proj_split = 1;              // largest split-K factor of the step's d x d projections on the 64x64 kernel
@@ -374,6 +374,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   if (const char* g3 = getenv("TTX_GEMM3_MAX_N")) s->gemm3_max_n = atoi(g3);
   if (const char* f2 = getenv("TTX_FFN2_SPLIT")) s->ffn2_split = std::max(1, atoi(f2));
   if (const char* ps = getenv("TTX_PROJ_SPLIT")) s->proj_split = std::max(1, atoi(ps));
+  if (const char* a3 = getenv("TTX_ATTN_V3")) s->attn_v3 = atoi(a3) != 0;
   if (const char* bt = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(bt));
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
@@ -522,6 +523,14 @@ static int launch_attn(ttx_session* s, hipStream_t st, const AttnArgs& a, int gr
   // step modes: q_per_group = RPS = 1 + N*D rows per running sequence.  Self-attention keys of one workgroup:
   // prefix (< max_keys) + front row + the rows of every draft with a query among its 64 rows.
   const int D = D1 - 1;
+  if constexpr (step) {
+    // the verify step: one wave per (sequence, head, 32 step rows), registers only — no key-count limit
+    if (s->attn_v3 && H % 4 == 0 && !s->attn_v1) {
+      hipLaunchKernelGGL((k_attn3<MODE>), dim3(groups, H / 4, cdiv(q_per_group, A3_QT)), dim3(256), 0, st, a);
+      HIP_TRY(hipGetLastError());
+      return TTX_OK;
+    }
+  }
   const int draft_keys = (D > 0) ? (std::min(N, (A2_QT + D - 2) / D + 1)) * D : 0;
   const int keys2 = (MODE == ATT_STEP_SELF) ? max_keys + 1 + draft_keys : max_keys;
   const size_t lds2 = attn2_lds_bytes(keys2, a2_qcap(q_per_group));

@@ -1229,6 +1229,201 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
+// Attention v3 for the verify step: ONE WAVE per (running sequence, head, 32 step rows), no LDS, no barrier.
+//
+// Everything stays in the layout the fp32 MFMA produces.  Scores are computed TRANSPOSED, S^T = K Q^T (A operand =
+// 32 keys of the tile, B operand = the 32 queries), so a lane (r, h) ends up with 16 scores of ONE query r (keys
+// (v&3) + 8(v>>2) + 4h of the tile): the online-softmax statistics of a query live in its own two lanes (one
+// exchange with lane^32), and the probabilities are already the B operand of the second product
+// O^T = V^T P^T in exactly the key pairing (own register t of the h = 0 lane with own register t of the h = 1 lane)
+// the MFMA contracts; its A operand V^T is 16 coalesced 128-B row reads per tile.  O^T again keeps one query per
+// lane, so rescaling by exp(m_old - m_new) and the final 1/l are per-lane scalars.  Keys are visited in tiles of
+// 32 in a fixed order: a row's arithmetic does not depend on the batch it sits in.
+// A3Tile = what one 32-key tile needs from memory, per lane.
+struct A3Tile {
+  float4 k0, k1, k2, k3;     // A operand of S^T: key key0 + r, dims 8g + 4h .. +3
+  float v[16];               // A operand of O^T: V[key(t, h)][r], key(t, h) = key0 + (t&3) + 8(t>>2) + 4h
+  int own;                   // validity word of key key0 + r (token / source-valid byte), balloted below
+};
+
+template <int MODE, typename KeyPtr, typename KeyOwn, typename KeyFlag, typename QFlag>
+__device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int nk, KeyPtr keyptr, KeyOwn keyown, KeyFlag keyflag,
+                                           QFlag qflag, float* out, int ldo, float scale) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  // B operand of S^T: query r, dims 8g + 4h .. +3 (rows past nq repeat the last query; they are never stored)
+  f32x4 qv[4];
+  {
+    const float* qp = q + (size_t)min(r, nq - 1) * ldq + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      qv[g] = *reinterpret_cast<const f32x4*>(qp + 8 * g);
+      qv[g] *= scale;
+    }
+  }
+  const int qf = qflag(min(r, nq - 1));
+  float m = -INFINITY, l = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[i] = 0.f;
+
+  // every load of a tile is unconditional (key indices clamped to nk - 1; such keys are masked): a conditional load
+  // costs a branch and a full vmcnt(0) round trip each
+  auto load_tile = [&](int key0) {
+    A3Tile tl;
+    const float *kp, *vp;
+    const int kown = min(key0 + r, nk - 1);
+    keyptr(kown, kp, vp);
+    tl.k0 = *reinterpret_cast<const float4*>(kp + 4 * h);
+    tl.k1 = *reinterpret_cast<const float4*>(kp + 4 * h + 8);
+    tl.k2 = *reinterpret_cast<const float4*>(kp + 4 * h + 16);
+    tl.k3 = *reinterpret_cast<const float4*>(kp + 4 * h + 24);
+    tl.own = keyown(kown);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float *kq, *vq;
+      keyptr(min(key0 + (t & 3) + 8 * (t >> 2) + 4 * h, nk - 1), kq, vq);
+      tl.v[t] = vq[r];
+    }
+    return tl;
+  };
+
+  const int ntiles = (nk + 31) >> 5;
+  A3Tile cur = load_tile(0);
+  for (int it = 0; it < ntiles; ++it) {
+    const int key0 = it * 32;
+    // the next tile's loads go out before this tile's arithmetic (the empty asm keeps them above it); the copy at the
+    // bottom of the loop is where they are waited for
+    A3Tile nxt = load_tile(min(it + 1, ntiles - 1) * 32);
+    asm volatile("" ::: "memory");
+    f32x16 sacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.x, qv[0].x, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.y, qv[0].y, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.z, qv[0].z, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.w, qv[0].w, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.x, qv[1].x, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.y, qv[1].y, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.z, qv[1].z, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.w, qv[1].w, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.x, qv[2].x, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.y, qv[2].y, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.z, qv[2].z, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.w, qv[2].w, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.x, qv[3].x, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.y, qv[3].y, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.z, qv[3].z, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.w, qv[3].w, sacc, 0, 0, 0);
+    // validity of the tile's 32 keys as a bit mask (lanes 0..31 hold keys key0 .. key0+31)
+    const unsigned valid = (unsigned)__ballot(cur.own != 0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int j = (t & 3) + 8 * (t >> 2) + 4 * h;
+      const int key = key0 + j;
+      const int kf = key < nk ? keyflag(key, (valid >> j) & 1u) : A2_MASKED;
+      sacc[t] = a2_visible(qf, kf) ? sacc[t] : -INFINITY;
+      mx = fmaxf(mx, sacc[t]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float base = (m_new == -INFINITY) ? 0.f : m_new;           // nothing visible yet: every exp below is exp(-inf) = 0
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      sacc[t] = __expf(sacc[t] - base);
+      rs += sacc[t];
+    }
+    rs += __shfl_xor(rs, 32);
+    const float alpha = __expf(m - base);                             // m = -inf -> 0
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] *= alpha;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) o = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[t], sacc[t], o, 0, 0, 0);
+    cur = nxt;
+  }
+  // o[v] = O[query r][dim (v&3) + 8(v>>2) + 4h]: four float4 per lane
+  if (r < nq) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float* op = out + (size_t)r * ldo + 4 * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 w = {o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + 8 * c) = w;
+    }
+  }
+}
+
+constexpr int A3_QT = 32;            // step rows per wave
+template <int MODE>
+__global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
+  static_assert(MODE == ATT_STEP_SELF || MODE == ATT_STEP_CROSS, "k_attn3 serves the verify step");
+  const int slot = blockIdx.x;
+  if (slot >= a.st->n_active) return;
+  const int head = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int hd = head * ATT_DH;
+  const int D = a.D, RPS = step_rps(a.N, a.D);
+  const int r0 = blockIdx.z * A3_QT;
+  const int nq = min(A3_QT, RPS - r0);
+  if (nq <= 0) return;
+  const int b = a.act_idx[slot];
+  const size_t srow0 = (size_t)slot * RPS;
+  if constexpr (MODE == ATT_STEP_SELF) {
+    const int f = a.front[b];
+    const int* tk = a.tok + (size_t)b * a.gen_ld;
+    const int pad = a.pad;
+    const float* kc = a.kcache + (size_t)b * a.cache_seq_stride + hd;
+    const float* vc = a.vcache + (size_t)b * a.cache_seq_stride + hd;
+    const float* kb = a.k + srow0 * a.ldkv + hd;
+    const float* vb = a.v + srow0 * a.ldkv + hd;
+    const int ld = a.ldkv, dd = a.d;
+    // keys: cached prefix [0,f) | step row 0 (position f) | the rows of every draft that has a query in this tile
+    const int rlast = r0 + nq - 1;
+    const int n_lo = (r0 == 0) ? 0 : (r0 - 1) / D;
+    const int n_hi = (rlast == 0) ? -1 : (rlast - 1) / D;
+    const int kr0 = 1 + n_lo * D;
+    const int n_draft_keys = (n_hi >= n_lo && D > 0) ? (n_hi - n_lo + 1) * D : 0;
+    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, f + 1 + n_draft_keys,
+                     [=](int key, const float*& kp, const float*& vp) {
+                       const bool cached = key < f;
+                       const int srow = (key == f) ? 0 : kr0 + (key - f - 1);
+                       const size_t off = cached ? (size_t)key * dd : (size_t)srow * ld;
+                       kp = (cached ? kc : kb) + off;
+                       vp = (cached ? vc : vb) + off;
+                     },
+                     [=](int key) { return tk[min(key, f)] != pad ? 1 : 0; },       // prefix / front token is a real token
+                     [=](int key, unsigned real) {
+                       const int kr = kr0 + max(key - f - 1, 0);
+                       const int kn = (kr - 1) / max(D, 1);
+                       const int draft_flag = a2_flag(kn - n_lo, kr - 1 - kn * D);
+                       return key <= f ? (real ? A2_ALL : A2_MASKED) : draft_flag;
+                     },
+                     [=](int qi) {
+                       const int qr = r0 + qi;
+                       if (qr == 0 || D == 0) return a2_flag(0x3fff, 0);
+                       const int qn = (qr - 1) / D;
+                       return a2_flag(qn - n_lo, qr - 1 - qn * D);
+                     },
+                     a.out + (srow0 + r0) * a.d + hd, a.d, a.scale);
+  } else {
+    const size_t mrow0 = (size_t)(a.src_of ? a.src_of[b] : b) * a.Lk;
+    const uint8_t* kvalid = a.key_pad + mrow0;
+    const float* kb = a.k + mrow0 * a.ldkv + hd;
+    const float* vb = a.v + mrow0 * a.ldkv + hd;
+    const int ld = a.ldkv;
+    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, a.Lk,
+                     [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
+                     [=](int key) { return (int)kvalid[key]; },
+                     [=](int, unsigned real) { return real ? A2_ALL : A2_MASKED; },
+                     [](int) { return 0; },
+                     a.out + (srow0 + r0) * a.d + hd, a.d, a.scale);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Embedding + positional row (pos + 1); one wave per token row, float4 per lane when d == 256.
 struct EmbedArgs {
   const float* table; const float* pe; float* X; int d;
