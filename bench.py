@@ -170,10 +170,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    # A batch on which the reference itself raises (a row finishing at a width beyond max_len) is skipped and not
+    # counted: its rows are reported as all-PAD and listed under "batches_reference_raises".
+    raised = []
     if a.inflight > 1:
-        outs = gen.generate_many(timed, in_flight=a.inflight, reorder=rows_sched)
+        outs = gen.generate_many(timed, in_flight=a.inflight, reorder=rows_sched, on_error="skip")
+        raised = list(gen.last_failed_batches)
     else:
-        outs = [gen.generate(b) for b in timed]
+        outs = []
+        for i, b in enumerate(timed):
+            try:
+                outs.append(gen.generate(b))
+            except tta.ReferenceError_:
+                outs.append(None)
+                raised.append(i)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -186,11 +196,15 @@ def main():
         elapsed = float(t.item())
 
     # ---- prediction gather: one collective at the end
+    outs = [o if o is not None else torch.full((timed[i].shape[0], 1, a.max_len), PAD, dtype=torch.int64, device=dev)
+            for i, o in enumerate(outs)]
     preds = torch.cat([o[:, 0, :] for o in outs])
     gathered = tta.dist.gather_predictions(preds.unsqueeze(1), world * preds.shape[0], dist)
     if rank == 0:
         assert gathered.shape[0] == world * preds.shape[0]
-    n_reactions = world * len(timed) * a.batch_size
+    counted = tta.dist.sum_counters({"reactions": sum(int(timed[i].shape[0]) for i in range(len(timed)) if i not in raised),
+                                     "raised": len(raised)}, dev, dist)
+    n_reactions = int(counted["reactions"])
     stats = dict(gen.stats_total)
     stats["model_calls"] = gen.model_calls_num
     finished = int((preds == EOS).any(dim=1).sum())
@@ -208,6 +222,7 @@ def main():
                    "schedule": ("rows of the K given batches regrouped by source length on the device, reference loop replayed "
                                 "per given batch (outputs and model_calls identical to per-batch generate)") if rows_sched
                                else "batches decoded as given"},
+        "batches_reference_raises": int(counted["raised"]),
         "model_calls": stats["model_calls"], "rows_finished_rank0": finished, "rows_rank0": int(preds.shape[0]),
         "accepted_per_step_per_row": stats["accepted_tokens"] / max(1, stats["produced_tokens"] - stats["accepted_tokens"]),
         "device_ms_encode_rank0": stats["encode_ms"], "device_ms_decode_rank0": stats["decode_ms"],
@@ -225,21 +240,30 @@ def main():
             g1 = make_gen(model)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            seq = [g1.generate(b) for b in timed]
+            seq = []
+            for i, b in enumerate(timed):
+                try:
+                    seq.append(g1.generate(b))
+                except tta.ReferenceError_:
+                    seq.append(None)
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t1
-            line["one_batch_at_a_time"] = {"value": len(timed) * a.batch_size / dt1, "unit": "reactions/s",
-                                           "identical_to_timed_outputs": all(torch.equal(x, y) for x, y in zip(seq, outs))}
+            ok1 = [i for i, o in enumerate(seq) if o is not None]
+            line["one_batch_at_a_time"] = {"value": sum(int(timed[i].shape[0]) for i in ok1) / dt1, "unit": "reactions/s",
+                                           "identical_to_timed_outputs": sorted(set(range(len(timed))) - set(ok1)) == sorted(raised)
+                                           and all(torch.equal(seq[i], outs[i]) for i in ok1)}
         if rows_sched and not a.timed_only:
             # the same K batches decoded as given (no regrouping), a.inflight of them at a time
             g2 = make_gen(model)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            given = g2.generate_many(timed, in_flight=a.inflight)
+            given = g2.generate_many(timed, in_flight=a.inflight, on_error="skip")
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
-            line["batches_as_given_in_flight"] = {"value": len(timed) * a.batch_size / dt2, "unit": "reactions/s",
-                                                  "identical_to_row_scheduled_outputs": all(torch.equal(x, y) for x, y in zip(given, outs)),
+            ok2 = [i for i, o in enumerate(given) if o is not None]
+            line["batches_as_given_in_flight"] = {"value": sum(int(timed[i].shape[0]) for i in ok2) / dt2, "unit": "reactions/s",
+                                                  "identical_to_row_scheduled_outputs": sorted(set(range(len(timed))) - set(ok2)) == sorted(raised)
+                                                  and all(torch.equal(given[i], outs[i]) for i in ok2),
                                                   "model_calls": g2.model_calls_num}
             line["device_model_calls"] = stats["device"]["model_calls"]
             line["device_src_tokens_padded"] = stats["device"]["src_tokens_padded"]
@@ -255,12 +279,15 @@ def main():
             ms, n, e = C.c_double(), C.c_int64(), C.c_double()
             if rows_sched:
                 # the timed region's workload: the same row groups, one after the other on the profiling session
-                pg.generate_many(timed, in_flight=1, reorder=True, group_size=gen.last_group_size)
+                pg.generate_many(timed, in_flight=1, reorder=True, group_size=gen.last_group_size, on_error="skip")
                 pm._lib.ttx_last_kernel_profile(pm.session, C.byref(ms), C.byref(n), C.byref(e))
                 gemm_ms, launches, empty_ms = ms.value, n.value, e.value
             else:
                 for b in timed:
-                    pg.generate(b)
+                    try:
+                        pg.generate(b)
+                    except tta.ReferenceError_:
+                        pass
                     pm._lib.ttx_last_kernel_profile(pm.session, C.byref(ms), C.byref(n), C.byref(e))
                     gemm_ms += ms.value
                     launches += n.value
@@ -294,13 +321,14 @@ def main():
             log("cpu baseline on", cores, "threads")
             om = OracleTransformer(config_from_state(sd, 8, PAD), sd)
             og = GreedySpeculativeOracle(om, a.max_len, a.draft_len, a.n_drafts, PAD, BOS, EOS, C_TOK)
-            sample = timed[:a.cpu_batches]
+            sample_idx = [i for i in range(len(timed)) if i not in raised][:a.cpu_batches]
+            sample = [timed[i] for i in sample_idx]
             with torch.inference_mode():
                 t1 = time.perf_counter()
                 cpu_out = [og.generate(b.cpu()) for b in sample]
                 cpu_s = time.perf_counter() - t1
-            same = sum(int(torch.equal(c[:, 0], o[:, 0].cpu())) for c, o in zip(cpu_out, outs))
-            rows_same = sum(int((c[:, 0] == o[:, 0].cpu()).all(dim=1).sum()) for c, o in zip(cpu_out, outs))
+            same = sum(int(torch.equal(c[:, 0], outs[i][:, 0].cpu())) for c, i in zip(cpu_out, sample_idx))
+            rows_same = sum(int((c[:, 0] == outs[i][:, 0].cpu()).all(dim=1).sum()) for c, i in zip(cpu_out, sample_idx))
             n_cpu = len(sample) * a.batch_size
             line["cpu_baseline"] = {"value": n_cpu / cpu_s, "unit": "reactions/s", "cores": cores, "kind": "port",
                                     "sample": f"first {len(sample)} timed batch(es) = {n_cpu} reactions of the same workload, "

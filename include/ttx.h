@@ -123,6 +123,8 @@ typedef struct ttx_gen_stats {
   int64_t kv_prefix_positions; /* sum over steps and running rows of the cached prefix length          */
   int64_t src_positions;       /* sum over steps of Bc*Ls (cross-attention keys read)                  */
   double  encode_ms, decode_ms;/* device time (HIP events on `stream`) of the two phases               */
+  int64_t status;              /* this batch's own status (TTX_OK, TTX_ERR_REFERENCE, ...): the *_many calls return the
+                                  first failure but decode every batch                                  */
 } ttx_gen_stats;
 
 /* TranslationInferenceGreedySpeculative.generate (src/decoding/speculative_decoding.py:39-174) with a

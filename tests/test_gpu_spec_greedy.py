@@ -197,3 +197,25 @@ def test_reference_error_cases(tta, tiny):
         tta.TranslationInferenceGreedySpeculative(tiny, 150, 10, 3, PAD, BOS, EOS, PAD).generate(src.cuda())
     out = tta.TranslationInferenceGreedySpeculative(tiny, 1, 1, 1, PAD, BOS, EOS, c).generate(src.cuda())
     assert out.shape == (10, 1, 1) and int((out != PAD).sum()) == 0     # `while size(1) < max_len` never entered
+
+
+def test_generate_many_skip_mode(tta, tiny):
+    """on_error="skip": batches on which the reference raises come back as None (both schedules), the others equal
+    per-batch generate."""
+    src, _, c, _ = fixture_tokens()
+    batches = []
+    for lo, hi in ((0, 3), (3, 4), (4, 8), (8, 10), (0, 10), (5, 9), (6, 7)):
+        sel = src[lo:hi]
+        batches.append(sel[:, :int((sel != PAD).sum(1).max())].cuda())
+    max_len, D, N = 45, 4, 2                        # four of these batches raise in the reference (see the test above)
+    ref, calls = _sequential(tta, tiny, batches, max_len, D, N, c)
+    bad = [i for i, o in enumerate(ref) if o is None]
+    assert bad and len(bad) < len(batches)
+    for reorder in (True, False):
+        g = tta.TranslationInferenceGreedySpeculative(tiny, max_len, D, N, PAD, BOS, EOS, c)
+        out = g.generate_many(batches, in_flight=3, reorder=reorder, group_size=4, on_error="skip")
+        assert sorted(g.last_failed_batches) == bad
+        for i, o in enumerate(out):
+            assert (o is None) == (i in bad)
+            if o is not None:
+                assert torch.equal(o, ref[i])

@@ -50,7 +50,7 @@ class GenParams(C.Structure):
 class GenStats(C.Structure):
     _fields_ = [("model_calls", C.c_int64), ("accepted_tokens", C.c_int64), ("produced_tokens", C.c_int64),
                 ("verified_positions", C.c_int64), ("kv_prefix_positions", C.c_int64), ("src_positions", C.c_int64),
-                ("encode_ms", C.c_double), ("decode_ms", C.c_double)]
+                ("encode_ms", C.c_double), ("decode_ms", C.c_double), ("status", C.c_int64)]
 
 
 # every symbol include/ttx.h declares: (name, restype, argtypes)

@@ -1146,6 +1146,7 @@ static int gen_finish_collect(GenJob& j) {
     }
   }
   j.phase = 0;
+  if (j.stats) j.stats->status = hs.error == 3 ? TTX_ERR_ROW_REPLAY : (hs.error ? TTX_ERR_REFERENCE : TTX_OK);
   if (hs.error == 3)
     return fail(TTX_ERR_ROW_REPLAY, "a row emitted PAD inside its sequence: what the reference does next depends on the other rows "
                                     "of its batch, so the batch must be decoded as given (ttx_greedy_speculative_generate_many)");

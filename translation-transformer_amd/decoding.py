@@ -79,7 +79,8 @@ class TranslationInferenceGreedySpeculative:
         self.last_stats = st
         return out
 
-    def generate_many(self, batches: list, in_flight: int = 4, reorder: bool = False, group_size: int | None = None) -> list:
+    def generate_many(self, batches: list, in_flight: int = 4, reorder: bool = False, group_size: int | None = None,
+                      on_error: str = "raise") -> list:
         """Decode several batches with up to `in_flight` of them on the GPU at once (one session + stream each;
         ttx_greedy_speculative_generate_many).  Returns one [B,1,max_len] tensor per batch, each identical to what
         ``generate`` returns for that batch; counters accumulate as if ``generate`` had been called per batch.
@@ -87,13 +88,20 @@ class TranslationInferenceGreedySpeculative:
         ``reorder=True`` decodes the rows in groups sorted by source length (less padding, rows of similar length
         finish together) through ttx_greedy_speculative_generate_rows and then replays the reference's width rule
         over the batches as passed (scheduling.replay_batch): outputs, ``model_calls_num`` and the error behaviour
-        stay those of per-batch ``generate`` calls."""
+        stay those of per-batch ``generate`` calls.
+
+        ``on_error="skip"``: a batch on which the reference raises (a row finishing at a width beyond max_len,
+        speculative_decoding.py:158) yields ``None`` in the returned list instead of ending the call; the indices are
+        kept in ``self.last_failed_batches``."""
         m = self.model
+        if on_error not in ("raise", "skip"):
+            raise ValueError("on_error must be 'raise' or 'skip'")
+        self.last_failed_batches = []
         if not batches:
             return []
         if reorder:
             try:
-                return self._generate_reordered(batches, in_flight, group_size)
+                return self._generate_reordered(batches, in_flight, group_size, on_error)
             except N.TtxError as e:
                 if e.code != N.TTX_ERR_ROW_REPLAY:
                     raise            # otherwise: a PAD inside a sequence; decode the batches as given
@@ -109,10 +117,17 @@ class TranslationInferenceGreedySpeculative:
         p = N.GenParams(self.max_len, self.draft_len, self.n_drafts, self.pad_token, self.bos_token, self.eos_token,
                         self.replace_token, 0)
         stats = (N.GenStats * n)()
-        N.check(m._lib.ttx_greedy_speculative_generate_many(sess, len(pool), n, src_p, Bs, Ls, C.byref(p), out_p, stats,
-                                                            m._stream()))
+        rc = m._lib.ttx_greedy_speculative_generate_many(sess, len(pool), n, src_p, Bs, Ls, C.byref(p), out_p, stats, m._stream())
+        if not (rc == N.TTX_ERR_REFERENCE and on_error == "skip"):
+            N.check(rc)
         t = self.stats_total
         for i, st in enumerate(stats):
+            if st.status != N.TTX_OK:                  # only reachable in skip mode: every batch was decoded, this one raises
+                if st.status != N.TTX_ERR_REFERENCE:
+                    N.check(int(st.status))
+                outs[i] = None
+                self.last_failed_batches.append(i)
+                continue
             self.model_calls_num += int(st.model_calls)
             for k in ("accepted_tokens", "produced_tokens", "verified_positions", "kv_prefix_positions", "src_positions",
                       "encode_ms", "decode_ms"):
@@ -121,7 +136,7 @@ class TranslationInferenceGreedySpeculative:
             t["batches"] += 1
         return outs
 
-    def _generate_reordered(self, batches: list, in_flight: int, group_size: int | None) -> list:
+    def _generate_reordered(self, batches: list, in_flight: int, group_size: int | None, on_error: str = "raise") -> list:
         from .scheduling import plan_row_groups, replay_batch
         m = self.model
         L, T = self.max_len, self.max_len + 1
@@ -175,6 +190,10 @@ class TranslationInferenceGreedySpeculative:
         for bi, B in enumerate(sizes):
             rep = replay_batch(traj[r0:r0 + B], fin[r0:r0 + B], L, self.draft_len, self.n_drafts)
             if rep.error:
+                if on_error == "skip":
+                    self.last_failed_batches.append(bi)
+                    r0 += B
+                    continue
                 failed = bi
                 break
             keep[r0:r0 + B] = torch.from_numpy(rep.finished)
@@ -205,8 +224,9 @@ class TranslationInferenceGreedySpeculative:
                                     "(speculative_decoding.py:158)")
         out_rows = torch.where(keep.to(m.device)[:, None], out_rows, torch.full_like(out_rows, self.pad_token))
         outs, r0 = [], 0
-        for B in sizes:
-            outs.append(out_rows[r0:r0 + B].unsqueeze(1).contiguous())
+        skipped = set(self.last_failed_batches)
+        for bi, B in enumerate(sizes):
+            outs.append(None if bi in skipped else out_rows[r0:r0 + B].unsqueeze(1).contiguous())
             r0 += B
         return outs
 
