@@ -123,6 +123,7 @@ typedef struct ttx_gen_stats {
   int64_t kv_prefix_positions; /* sum over steps and running rows of the cached prefix length          */
   int64_t src_positions;       /* sum over steps of Bc*Ls (cross-attention keys read)                  */
   double  encode_ms, decode_ms;/* device time (HIP events on `stream`) of the two phases               */
+  int64_t src_tokens_padded;   /* encoder positions computed: rows x padded length, summed over encoder passes         */
   int64_t status;              /* this batch's own status (TTX_OK, TTX_ERR_REFERENCE, ...): the *_many calls return the
                                   first failure but decode every batch                                  */
 } ttx_gen_stats;
@@ -214,6 +215,19 @@ int ttx_greedy_speculative_generate_rows(ttx_session** sessions, int n_sessions,
                                          const int64_t* const* d_src, const int* B, const int* Ls,
                                          const ttx_gen_params* p, int64_t* const* d_out, int16_t* const* d_traj,
                                          int32_t* const* d_fin_step, ttx_gen_stats* stats, void* stream);
+
+/* The same contract as ttx_greedy_speculative_generate_rows with continuous batching: rows are not cut into fixed
+ * groups; every session keeps a pool of up to `capacity` slots and admits the next rows of the work list (encoder,
+ * cross K/V, drafts, slot state) whenever at least a quarter of its slots are free, so the verify step keeps
+ * close to capacity * (1 + n_drafts * draft_len) rows until the list is exhausted.  d_src int64 [R_total][Ls_all] holds
+ * ALL rows right-padded, sorted by length, longest first; h_len (HOST, int32 [R_total]) their lengths (position after
+ * the last non-PAD token).  d_out int64 [R_total][max_len], d_traj int16 [R_total][max_len + 1], d_fin_step int32
+ * [R_total] as in ttx_greedy_speculative_generate_rows, in the order of d_src.  `stats` (zero it first) receives the
+ * sums over all sessions; stats->model_calls counts the verify steps the device executed.  Returns
+ * TTX_ERR_ROW_REPLAY like the rows call. */
+int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int n_sessions, const int64_t* d_src, int R_total, int Ls_all,
+                                         const int32_t* h_len, int capacity, const ttx_gen_params* p, int64_t* d_out,
+                                         int16_t* d_traj, int32_t* d_fin_step, ttx_gen_stats* stats, void* stream);
 
 /* Host-side string work either side of the hot path (no GPU) ------------------------------------
  * ChemSMILESTokenizer (src/data_handling/tokenizer_smiles.py:8-39), the pad_sequence collate

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     assert C.sizeof(N.Config) == 10 * 4
     assert C.sizeof(N.GenParams) == 8 * 4
-    assert C.sizeof(N.GenStats) == 6 * 8 + 2 * 8 + 8
+    assert C.sizeof(N.GenStats) == 6 * 8 + 2 * 8 + 2 * 8
     assert C.sizeof(N.Tensor) == 24
 
 

@@ -19,7 +19,7 @@ g.generate_many(warm * inflight, in_flight=inflight, reorder=True)
 def run(mode, gs, fl):
     g = tta.TranslationInferenceGreedySpeculative(model, 200, 10, 3, PAD, BOS, EOS, C_TOK)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    g.generate_many(timed, in_flight=fl, reorder=mode, group_size=gs)
+    g.generate_many(timed, in_flight=fl, reorder=mode, group_size=gs, on_error="skip")
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"reorder={mode} group={gs} in_flight={fl}: {len(timed) * 32 / dt:8.1f} reactions/s  {dt * 1e3:7.1f} ms  "
           f"calls={g.model_calls_num} device_calls={g.stats_total.get('device_model_calls')}", flush=True)

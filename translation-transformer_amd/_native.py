@@ -50,7 +50,8 @@ class GenParams(C.Structure):
 class GenStats(C.Structure):
     _fields_ = [("model_calls", C.c_int64), ("accepted_tokens", C.c_int64), ("produced_tokens", C.c_int64),
                 ("verified_positions", C.c_int64), ("kv_prefix_positions", C.c_int64), ("src_positions", C.c_int64),
-                ("encode_ms", C.c_double), ("decode_ms", C.c_double), ("status", C.c_int64)]
+                ("encode_ms", C.c_double), ("decode_ms", C.c_double), ("src_tokens_padded", C.c_int64),
+                ("status", C.c_int64)]
 
 
 # every symbol include/ttx.h declares: (name, restype, argtypes)
@@ -77,6 +78,8 @@ SYMBOLS = {
     "ttx_greedy_speculative_generate_rows": (C.c_int, [C.POINTER(_VP), _I, _I, C.POINTER(_VP), C.POINTER(C.c_int),
                                                       C.POINTER(C.c_int), C.POINTER(GenParams), C.POINTER(_VP),
                                                       C.POINTER(_VP), C.POINTER(_VP), C.POINTER(GenStats), _VP]),
+    "ttx_greedy_speculative_generate_pool": (C.c_int, [C.POINTER(_VP), _I, _VP, _I, _I, C.POINTER(C.c_int32), _I,
+                                                      C.POINTER(GenParams), _VP, _VP, _VP, C.POINTER(GenStats), _VP]),
     "ttx_nucleus_mask": (C.c_int, [_VP, _VP, _I, _I, C.c_float, _I, C.c_float, _VP, _VP]),
     "ttx_accepted_lengths": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _I, _VP, _VP]),
     "ttx_ragged_topk": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),

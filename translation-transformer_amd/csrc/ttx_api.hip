@@ -270,6 +270,8 @@ struct ttx_session {
   Buf tok_tgt, mem_pad_tmp;
   // loop
   Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf, dbg_self, dbg_cross, haspad, traj, fin_step;
+  // slot pool (continuous batching)
+  Buf rstep, row_of, src_len, new_slot, pool_io, memkv_new, valid_new, drafts_new;
   // snapshot of one verify step for the logits parity test (ttx_gen_params.want_logits)
   Buf snap_logits, snap_act, snap_front, snap_gen, snap_state;
   int snap_B = 0, snap_rps = 0, snap_gen_ld = 0, snap_step = 0;
@@ -310,7 +312,8 @@ struct ttx_session {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
   ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
-                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &traj, &fin_step, &tk[0], &tk[1], &tv[0], &tv[1],
+                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &traj, &fin_step, &rstep, &row_of, &src_len, &new_slot,
+                                 &pool_io, &memkv_new, &valid_new, &drafts_new, &tk[0], &tk[1], &tv[0], &tv[1],
                                  &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active, &dbg_gemm,
                                  &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state, &leaf_score, &leaf_tok, &leaf_cnt,
                                  &beam_summary}) all.push_back(b); }
@@ -761,6 +764,7 @@ struct StepCtx {
   const float* kcache = nullptr;   // null: the session's greedy-path caches
   const float* vcache = nullptr;
   const int* src_of = nullptr;     // running row -> source row (tree decoding)
+  const int* src_len = nullptr;    // slot pool: source keys per slot
   bool want_argmax = true;
 };
 
@@ -813,7 +817,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     ca.q = q2; ca.ldq = d; ca.k = s->memkv.as<float>() + (size_t)l * 2 * d; ca.v = ca.k + d; ca.ldkv = Ld * 2 * d;
     ca.out = ao; ca.d = d; ca.scale = scale; ca.Lk = k.Ls; ca.key_pad = s->src_valid.as<uint8_t>();
     ca.st = dst; ca.act_idx = s->act_idx.as<int>(); ca.front = s->front.as<int>(); ca.N = k.N; ca.D = k.D;
-    ca.src_of = k.src_of;
+    ca.src_of = k.src_of; ca.src_len = k.src_len;
     if (s->attn_debug && l == Ld - 1) ca.dbg = s->dbg_cross.as<unsigned long long>();
     TTX_TRY(launch_attn<ATT_STEP_CROSS>(s, st, ca, k.B, H, RPS, k.Ls, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
@@ -1065,6 +1069,32 @@ static int gen_finish_enqueue(GenJob& j) {
   return TTX_OK;
 }
 
+// GEMM event pairs of the work just finished on `st` -> the session's running sums (bench.py roofline).
+static void collect_gemm_profile(ttx_session* s, hipStream_t st) {
+  if (!s->profile) return;
+  // summed over the generate calls since the last ttx_last_kernel_profile read
+  s->prof_launches += (long long)s->ev_used;
+  for (size_t i = 0; i < s->ev_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) s->prof_ms += ms;
+  }
+  s->ev_used = 0;
+  // what an empty event pair costs on this stream (no kernel between the two records): reported beside the raw sum
+  if (s->prof_empty_pair_ms < 0 && s->ev_pool.size() >= 64) {
+    for (int i = 0; i < 64; ++i) {
+      (void)hipEventRecord(s->ev_pool[i].first, st);
+      (void)hipEventRecord(s->ev_pool[i].second, st);
+    }
+    (void)hipStreamSynchronize(st);
+    double acc = 0;
+    for (int i = 0; i < 64; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) acc += ms;
+    }
+    s->prof_empty_pair_ms = acc / 64.0;
+  }
+}
+
 static int gen_finish_collect(GenJob& j) {
   ttx_session* s = j.s;
   const DecState& hs = *s->host_state;
@@ -1075,34 +1105,14 @@ static int gen_finish_collect(GenJob& j) {
     j.stats->verified_positions = hs.verified_positions;
     j.stats->kv_prefix_positions = hs.kv_prefix_positions;
     j.stats->src_positions = hs.src_positions;
+    j.stats->src_tokens_padded = (long long)j.g.k.B * j.g.k.Ls;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_a, s->ev_b));
     j.stats->encode_ms = ms;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_b, s->ev_c));
     j.stats->decode_ms = ms;
   }
-  if (s->profile) {
-    // summed over the generate calls since the last ttx_last_kernel_profile read
-    s->prof_launches += (long long)s->ev_used;
-    for (size_t i = 0; i < s->ev_used; ++i) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) s->prof_ms += ms;
-    }
-    // what an empty event pair costs on this stream (no kernel between the two records): reported beside the raw sum
-    if (s->prof_empty_pair_ms < 0 && s->ev_pool.size() >= 64) {
-      for (int i = 0; i < 64; ++i) {
-        (void)hipEventRecord(s->ev_pool[i].first, j.st);
-        (void)hipEventRecord(s->ev_pool[i].second, j.st);
-      }
-      (void)hipStreamSynchronize(j.st);
-      double acc = 0;
-      for (int i = 0; i < 64; ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) acc += ms;
-      }
-      s->prof_empty_pair_ms = acc / 64.0;
-    }
-  }
+  collect_gemm_profile(s, j.st);
   if (s->gemm_debug && s->dbg_gemm.p) {
     // diagnostic: phases of the workgroups of the last GEMM launch with N == TTX_GEMM_DEBUG
     // (stamps: 0 start, 1 row count known, 2 first K tile staged, 3 MFMA loop done, 4 stores drained)
@@ -1206,6 +1216,256 @@ extern "C" int ttx_greedy_generate(ttx_session* s, const int64_t* d_src, int B, 
 // Several batches in flight on one GPU: batch i is decoded on session i % n_sessions, each
 // session on its own stream; one host thread round-robins over the sessions, enqueueing the next verify step of
 // whichever session has published its previous one.  Outputs per batch are identical to the one-at-a-time call.
+// ------------------------------------------------------------------------------------------------
+// Slot pool: continuous batching under the per-row rule.  A session owns `C` slots; whenever enough of them are free
+// the next rows of the (length-sorted) work list are encoded and admitted, so the verify step keeps close to
+// C * (1 + N*D) rows from the first step to the last instead of decaying with every retiring sequence, and there is
+// no tail of half-empty groups.  The step graph has one shape per session (C, Ls_cap): captured once.
+struct PoolJob {
+  ttx_session* s = nullptr;
+  hipStream_t st = nullptr;
+  GenCtx g{};
+  int C = 0, Ls_cap = 0;
+  int launched = 0;
+  int phase = 0;            // 0 not started, 1 running, 2 finishing, 3 done
+  int admits = 0;
+  long long admitted_rows = 0, src_tokens_padded = 0;
+};
+
+static int pool_start(PoolJob& j, ttx_session* s, hipStream_t st, int C, int Ls_cap, const ttx_gen_params* p, int64_t* d_out,
+                      int16_t* d_traj, int32_t* d_fin) {
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
+  const int N = p->n_drafts, D = p->draft_len, D1 = D + 1, max_len = p->max_len;
+  j.s = s; j.st = st; j.C = C; j.Ls_cap = Ls_cap; j.launched = 0; j.admits = 0; j.admitted_rows = 0; j.src_tokens_padded = 0;
+  s->snap_step = 0;
+  GenCtx& g = j.g;
+  g = GenCtx{};
+  g.k.B = C; g.k.Ls = Ls_cap; g.k.N = N; g.k.D = D; g.k.max_len = max_len; g.k.p = *p;
+  g.k.Lc = max_len + D1;
+  g.k.gen_ld = max_len + D + 2;
+  const size_t Mmax = (size_t)C * step_rps(N, D);
+  const size_t kv_row = (size_t)Ld * 2 * d;
+  const uint64_t gen_before = s->alloc_generation;
+  g_alloc_gen = &s->alloc_generation;
+  TTX_TRY(ensure(s->tok_src, (size_t)C * Ls_cap * 4, st));
+  TTX_TRY(ensure(s->valid_new, (size_t)C * Ls_cap, st));
+  TTX_TRY(ensure(s->src_valid, (size_t)C * Ls_cap, st));
+  TTX_TRY(ensure(s->memory, (size_t)C * Ls_cap * d * 4, st));
+  TTX_TRY(ensure(s->memkv_new, (size_t)C * Ls_cap * kv_row * 4, st));
+  TTX_TRY(ensure(s->memkv, (size_t)C * Ls_cap * kv_row * 4, st));
+  TTX_TRY(ensure(s->drafts, (size_t)C * N * D * 4, st));
+  TTX_TRY(ensure(s->drafts_new, (size_t)C * N * D * 4, st));
+  TTX_TRY(ensure(s->gen, (size_t)C * g.k.gen_ld * 4, st));
+  for (Buf* b : {&s->front, &s->act_idx, &s->haspad, &s->rstep, &s->row_of, &s->src_len, &s->new_slot}) TTX_TRY(ensure(*b, (size_t)C * 4, st));
+  TTX_TRY(ensure(s->rec, (size_t)C * sizeof(CopyRec), st));
+  TTX_TRY(ensure(s->pred, Mmax * 4, st));
+  TTX_TRY(ensure(s->state, sizeof(DecState), st));
+  TTX_TRY(ensure(s->pool_io, sizeof(PoolIo), st));
+  TTX_TRY(ensure(s->logits, Mmax * V * 4, st));
+  TTX_TRY(ensure(s->kcache, (size_t)Ld * C * g.k.Lc * d * 4, st));
+  TTX_TRY(ensure(s->vcache, (size_t)Ld * C * g.k.Lc * d * 4, st));
+  const size_t Macts = std::max(Mmax, (size_t)C * Ls_cap);
+  TTX_TRY(ensure_acts(s, st, Macts, 1));
+  TTX_TRY(ensure(s->qkv, std::max((size_t)Ld * Mmax, (size_t)C * Ls_cap) * 3 * d * 4, st));
+  TTX_TRY(ensure(s->slab, sizeof(float) * 16 * Macts * d, st));
+  g_alloc_gen = nullptr;
+  if (s->alloc_generation != gen_before) s->drop_graphs();
+
+  s->ev_used = 0;
+  HIP_TRY(hipEventRecord(s->ev_a, st));
+  PoolIo io{d_out, d_traj, d_fin, max_len + 1, 0};
+  HIP_TRY(hipMemcpyAsync(s->pool_io.p, &io, sizeof(io), hipMemcpyHostToDevice, st));   // pageable source: copied before return
+  g.la.st = s->state.as<DecState>(); g.la.act_idx = s->act_idx.as<int>(); g.la.front = s->front.as<int>();
+  g.la.gen = s->gen.as<int>(); g.la.gen_ld = g.k.gen_ld; g.la.drafts = s->drafts.as<int>(); g.la.pred = s->pred.as<int>();
+  g.la.rec = s->rec.as<CopyRec>(); g.la.out = nullptr; g.la.haspad = s->haspad.as<int>();
+  HostInfo* dev_info = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&dev_info, (void*)s->host_info, 0));
+  g.la.host = dev_info;
+  g.la.B = C; g.la.N = N; g.la.D = D; g.la.Ls = Ls_cap; g.la.max_len = max_len; g.la.pad = p->pad_token; g.la.bos = p->bos_token;
+  g.la.eos = p->eos_token;
+  g.la.row_rule = 1; g.la.traj = nullptr; g.la.traj_ld = max_len + 1; g.la.fin_step = nullptr;
+  g.la.pool = 1; g.la.rstep = s->rstep.as<int>(); g.la.row_of = s->row_of.as<int>(); g.la.io = s->pool_io.as<PoolIo>();
+  g.k.src_len = s->src_len.as<int>();
+  g.kc.st = s->state.as<DecState>(); g.kc.rec = s->rec.as<CopyRec>(); g.kc.qkv = s->qkv.as<float>();
+  g.kc.qkv_layer_stride = (long long)Mmax * 3 * d;
+  g.kc.kcache = s->kcache.as<float>(); g.kc.vcache = s->vcache.as<float>();
+  g.kc.cache_seq_stride = (long long)g.k.Lc * d; g.kc.cache_layer_stride = (long long)C * g.k.Lc * d;
+  g.kc.N = N; g.kc.D = D; g.kc.d = d;
+  s->host_info->stop = 0; s->host_info->steps_done = 0; s->host_info->width = 1; s->host_info->n_active = 0;
+  hipLaunchKernelGGL(k_pool_init, dim3(4), dim3(256), 0, st, g.la);
+  HIP_TRY(hipGetLastError());
+  j.phase = 1;
+  return TTX_OK;
+}
+
+// Encode R new rows (rows first_row .. first_row+R-1 of the caller's sorted matrix, Ls_new columns of it) and hand
+// them free slots.
+static int pool_admit(PoolJob& j, const int64_t* d_src_rows, int ld_src, int R, int Ls_new, int first_row, int64_t* d_out,
+                      int16_t* d_traj, int32_t* d_fin) {
+  ttx_session* s = j.s;
+  hipStream_t st = j.st;
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const StepCtx& k = j.g.k;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers;
+  const int kv_row = Ld * 2 * d;
+  hipLaunchKernelGGL(k_prepare_tokens_2d, dim3(cdiv(R * Ls_new, 256)), dim3(256), 0, st, d_src_rows, ld_src, s->tok_src.as<int>(),
+                     s->valid_new.as<uint8_t>(), R, Ls_new, c.pad_token);
+  HIP_TRY(hipGetLastError());
+  TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->valid_new.as<uint8_t>(), R, Ls_new, s->memory.as<float>()));
+  TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv_new.as<float>(),
+                      kv_row, nullptr, R * Ls_new, kv_row, d, false, 0, 0));
+  TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls_new, 1, R, Ls_new - 1, k.N, k.D, k.p.eos_token, k.p.pad_token,
+                                  k.p.replace_token, s->drafts_new.as<int>()));
+  PoolAdmitArgs a{};
+  a.st = s->state.as<DecState>(); a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>(); a.haspad = s->haspad.as<int>();
+  a.rstep = s->rstep.as<int>(); a.row_of = s->row_of.as<int>(); a.src_len = s->src_len.as<int>(); a.new_slot = s->new_slot.as<int>();
+  a.host = j.g.la.host; a.B = j.C; a.N = k.N; a.D = k.D; a.R = R; a.first_row = first_row; a.Ls_new = Ls_new;
+  hipLaunchKernelGGL(k_pool_admit, dim3(1), dim3(256), (size_t)j.C * 4, st, a);
+  HIP_TRY(hipGetLastError());
+  PoolFillArgs f{};
+  f.new_slot = s->new_slot.as<int>(); f.R = R; f.gen = s->gen.as<int>(); f.gen_ld = k.gen_ld; f.bos = k.p.bos_token; f.pad = k.p.pad_token;
+  f.drafts = s->drafts.as<int>(); f.drafts_new = s->drafts_new.as<int>(); f.nd = k.N * k.D;
+  f.src_valid = s->src_valid.as<uint8_t>(); f.valid_new = s->valid_new.as<uint8_t>(); f.Ls_cap = j.Ls_cap; f.Ls_new = Ls_new;
+  f.memkv = s->memkv.as<float>(); f.memkv_new = s->memkv_new.as<float>(); f.kv_row = kv_row;
+  f.out_rows = d_out; f.traj_rows = d_traj; f.fin_rows = d_fin; f.max_len = k.max_len; f.traj_ld = k.max_len + 1; f.first_row = first_row;
+  hipLaunchKernelGGL(k_pool_fill, dim3(R, 1 + Ls_new), dim3(256), 0, st, f);
+  HIP_TRY(hipGetLastError());
+  ++j.admits;
+  j.admitted_rows += R;
+  j.src_tokens_padded += (long long)R * Ls_new;
+  return TTX_OK;
+}
+
+static int pool_launch_step(PoolJob& j) {
+  ttx_session* s = j.s;
+  const StepCtx& k = j.g.k;
+  const int kcap = k.max_len;
+  const bool use_graph = s->use_graphs && !s->profile;
+  GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, 3, kcap};
+  auto it = s->graphs.find(key);
+  if (!use_graph || (it == s->graphs.end() && !s->warmed.count(key))) {
+    s->warmed.insert(key);          // first use of a shape runs eagerly once (function attributes are set outside capture)
+    TTX_TRY(run_step(s, j.st, k, kcap));
+    TTX_TRY(launch_accept_and_commit(s, j.st, j.g, false));
+    ++j.launched;
+    return TTX_OK;
+  }
+  if (it == s->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipStreamBeginCapture(j.st, hipStreamCaptureModeThreadLocal));
+    int rc = run_step(s, j.st, k, kcap);
+    if (rc == TTX_OK) rc = launch_accept_and_commit(s, j.st, j.g, false);
+    hipError_t e = hipStreamEndCapture(j.st, &graph);
+    if (rc != TTX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(TTX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(TTX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    if (s->graphs.size() > 512) s->drop_graphs();
+    it = s->graphs.emplace(key, exec).first;
+  }
+  HIP_TRY(hipGraphLaunch(it->second, j.st));
+  ++j.launched;
+  return TTX_OK;
+}
+
+extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int n_sessions, const int64_t* d_src, int R_total,
+                                                    int Ls_all, const int32_t* h_len, int capacity, const ttx_gen_params* p,
+                                                    int64_t* d_out, int16_t* d_traj, int32_t* d_fin_step, ttx_gen_stats* stats,
+                                                    void* stream) {
+  if (!sessions || n_sessions <= 0 || !d_src || R_total < 0 || !h_len || capacity <= 0 || capacity > 4096 || !p || !d_out || !d_traj ||
+      !d_fin_step)
+    return fail(TTX_ERR_INVALID, "bad argument to ttx_greedy_speculative_generate_pool");
+  if (R_total == 0) return TTX_OK;
+  if (p->max_len > 32000) return fail(TTX_ERR_INVALID, "max_len too large for the int16 trace");
+  // rows must come longest first: the first row fixes the slot width
+  int Ls_cap = std::max(2, (int)h_len[0]);
+  for (int i = 1; i < R_total; ++i)
+    if (h_len[i] > h_len[i - 1]) return fail(TTX_ERR_INVALID, "rows must be sorted by length, longest first");
+  if (Ls_cap > Ls_all) return fail(TTX_ERR_INVALID, "row length beyond the source matrix width");
+  TTX_TRY(gen_validate(sessions[0], d_src, capacity, Ls_cap, p, d_out, false));
+  HIP_TRY(hipSetDevice(sessions[0]->m->device));
+  release_retired();
+  hipEvent_t ready;
+  HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ready, (hipStream_t)stream));
+  const int n_jobs = std::min(n_sessions, cdiv(R_total, std::max(1, capacity / 2)));
+  const int C = std::min(capacity, std::max(1, cdiv(R_total, n_jobs)));      // never more slots than a fair share of the rows
+  std::vector<PoolJob> jobs(n_jobs);
+  int rc_final = TTX_OK;
+  for (int i = 0; i < n_jobs && rc_final == TTX_OK; ++i) {
+    ttx_session* s = sessions[i];
+    if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamWaitEvent(s->own_stream, ready, 0));
+    rc_final = pool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, d_out, d_traj, d_fin_step);
+  }
+  const int min_admit = std::max(1, C / 4);
+  int cursor = 0, done = 0;
+  while (done < n_jobs && rc_final == TTX_OK) {
+    bool progressed = false;
+    for (int i = 0; i < n_jobs && rc_final == TTX_OK; ++i) {
+      PoolJob& j = jobs[i];
+      ttx_session* s = j.s;
+      volatile HostInfo* hi = s->host_info;
+      if (j.phase == 1) {
+        if (j.launched > 0 && hi->steps_done < j.launched) continue;          // the step in flight has not published yet
+        int n_act = (j.launched == 0) ? 0 : hi->n_active;
+        const int free_slots = C - n_act;
+        if (cursor < R_total && (n_act == 0 || free_slots >= min_admit)) {
+          const int take = std::min(free_slots, R_total - cursor);
+          const int Ls_new = std::max(2, (int)h_len[cursor]);                 // longest of the chunk (rows are sorted)
+          rc_final = pool_admit(j, d_src + (size_t)cursor * Ls_all, Ls_all, take, Ls_new, cursor, d_out, d_traj, d_fin_step);
+          if (rc_final != TTX_OK) break;
+          cursor += take;
+          n_act += take;
+        }
+        if (n_act == 0) {
+          HIP_TRY(hipEventRecord(s->ev_c, j.st));
+          HIP_TRY(hipMemcpyAsync(s->host_state, s->state.as<DecState>(), sizeof(DecState), hipMemcpyDeviceToHost, j.st));
+          HIP_TRY(hipEventRecord(s->ev_done, j.st));
+          j.phase = 2;
+        } else {
+          if (j.launched > (long long)(p->max_len + 2) * (R_total + 1)) { rc_final = fail(TTX_ERR_HIP, "decode loop failed to terminate"); break; }
+          rc_final = pool_launch_step(j);
+        }
+        progressed = true;
+      } else if (j.phase == 2) {
+        if (hipEventQuery(s->ev_done) == hipSuccess) {
+          const DecState& hs = *s->host_state;
+          if (stats) {
+            stats->model_calls += hs.steps;
+            stats->accepted_tokens += hs.accepted;
+            stats->produced_tokens += hs.produced;
+            stats->verified_positions += hs.verified_positions;
+            stats->kv_prefix_positions += hs.kv_prefix_positions;
+            stats->src_positions += hs.src_positions;
+            stats->src_tokens_padded += j.src_tokens_padded;
+            collect_gemm_profile(s, j.st);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s->ev_a, s->ev_c) == hipSuccess) stats->decode_ms += ms;
+          }
+          if (hs.error == 3 && rc_final == TTX_OK)
+            rc_final = fail(TTX_ERR_ROW_REPLAY, "a row emitted PAD inside its sequence: decode the batches as given");
+          else if (hs.error && rc_final == TTX_OK)
+            rc_final = fail(TTX_ERR_HIP, "slot pool bookkeeping failed (admitted more rows than free slots)");
+          j.phase = 3;
+          ++done;
+          progressed = true;
+        }
+      }
+    }
+    if (!progressed) __builtin_ia32_pause();
+  }
+  for (int i = 0; i < n_jobs; ++i) (void)hipStreamSynchronize(jobs[i].s->own_stream);
+  (void)hipEventDestroy(ready);
+  if (stats) stats->status = rc_final;
+  return rc_final;
+}
+
 static int generate_many_impl(ttx_session** sessions, int n_sessions, int n_batches, const int64_t* const* d_src, const int* B,
                               const int* Ls, const ttx_gen_params* p, int64_t* const* d_out, int16_t* const* d_traj,
                               int32_t* const* d_fin, ttx_gen_stats* stats, void* stream) {

@@ -39,7 +39,7 @@ struct CopyRec { int b, best, nacc, front_old, flags; };   // flags: 1 finished 
 
 // Host-mapped (pinned) words the accept kernels publish after every step; the host polls them instead of
 // synchronising the stream.
-struct HostInfo { int stop; int steps_done; int width; int pad_; };
+struct HostInfo { int stop; int steps_done; int width; int n_active; };
 
 // ------------------------------------------------------------------------------------------------
 // GEMM:  Y[m, n] = sum_k X[m, k] * W[n, k]   (torch.nn.Linear layout: both operands K-contiguous)
@@ -819,6 +819,7 @@ struct AttnArgs {
   // step modes
   const DecState* st; const int* act_idx; const int* front;
   const int* src_of;               // step modes: running row -> source row of the encoder memory (null: identity)
+  const int* src_len;              // STEP_CROSS: keys of each row's source (null: Lk for every row) — slot pool
   const float* kcache; const float* vcache; long long cache_seq_stride;  // floats per sequence in the cache
   int gen_ld; int N; int D;
   unsigned long long* dbg;         // diagnostic builds only: per-block phase stamps (100 MHz realtime clock)
@@ -1414,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
     const float* kb = a.k + mrow0 * a.ldkv + hd;
     const float* vb = a.v + mrow0 * a.ldkv + hd;
     const int ld = a.ldkv;
-    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, a.Lk,
+    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, a.src_len ? a.src_len[b] : a.Lk,
                      [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                      [=](int key) { return (int)kvalid[key]; },
                      [=](int, unsigned real) { return real ? A2_ALL : A2_MASKED; },
@@ -1550,8 +1551,12 @@ struct LoopArgs {
   // per-row width rule (ttx_gen_params.row_rule): every row decodes as if it were alone in its batch and its front after
   // every step is recorded, so a scheduler may regroup rows freely and still reproduce each original batch exactly
   int row_rule; short* traj; int traj_ld; int* fin_step;
+  // slot pool (continuous batching, implies row_rule): a slot is re-used by a new row as soon as its row retires, so
+  // a row's step count, its position in the caller's arrays and the output pointers live beside the slot state
+  int pool; int* rstep; int* row_of; const struct PoolIo* io;
   int B, N, D, Ls, max_len, pad, bos, eos;
 };
+struct PoolIo { int64_t* out; short* traj; int* fin_step; int traj_ld; int pad_; };
 
 __global__ void k_loop_init(LoopArgs a) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1617,9 +1622,17 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     a.front[b] = f + bacc + 1;
     int flags = fin ? 1 : 0;
     if (a.row_rule) {
-      const int it = st->steps + 1;                    // all rows of this device batch started together
-      if (it < a.traj_ld) a.traj[(size_t)b * a.traj_ld + it] = (short)(f + bacc + 1);
-      if (fin) a.fin_step[b] = it;
+      int it = st->steps + 1;                          // all rows of a device batch start together ...
+      short* trow = a.traj + (size_t)b * a.traj_ld;
+      int* finp = a.fin_step + b;
+      if (a.pool) {                                    // ... rows of a slot pool do not
+        it = a.rstep[b] + 1;
+        a.rstep[b] = it;
+        trow = a.io->traj + (size_t)a.row_of[b] * a.traj_ld;
+        finp = a.io->fin_step + a.row_of[b];
+      }
+      if (it < a.traj_ld) trow[it] = (short)(f + bacc + 1);
+      if (fin) *finp = it;
       // alone in a batch this row would see width f + D + 2 after this step and stop once that reaches max_len (:93)
       else if (f + D1 + 1 >= a.max_len) flags = 2;
     }
@@ -1659,7 +1672,8 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     if (a.rec[slot].flags == 1) {                   // uniform over the block
       const int b = a.rec[slot].b;
       const int* g = a.gen + (size_t)b * a.gen_ld;
-      for (int c = threadIdx.x; c < wout; c += blockDim.x) a.out[(size_t)b * a.max_len + c] = g[c];
+      int64_t* orow = a.pool ? a.io->out + (size_t)a.row_of[b] * a.max_len : a.out + (size_t)b * a.max_len;
+      for (int c = threadIdx.x; c < wout; c += blockDim.x) orow[c] = g[c];
     }
   }
   __syncthreads();
@@ -1695,9 +1709,108 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     st->r_rows = stop ? 0 : nn * a.N;
     st->m_rows = stop ? 0 : nn * RPS;
     a.host->width = width;
-    a.host->steps_done = st->steps;
+    a.host->n_active = stop ? 0 : nn;
     a.host->stop = stop;
     __threadfence_system();
+    a.host->steps_done = st->steps;                  // last: the host reads the other words once it sees this one move
+    __threadfence_system();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Slot pool (continuous batching under the per-row rule).  The pool has B slots; k_pool_init empties it, k_pool_admit
+// hands free slots to R new rows (encoder output, cross K/V and drafts of those rows were just computed into
+// compact staging buffers), k_pool_fill moves the staged data into the slots.  The verify step and k_accept are the
+// ones of the batch path: they only ever see `act_idx` and per-slot state.
+__global__ void k_pool_init(LoopArgs a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = tid; i < a.B; i += gridDim.x * blockDim.x) { a.act_idx[i] = 0; a.front[i] = 0; a.haspad[i] = 0; a.rstep[i] = 0; a.row_of[i] = 0; }
+  if (tid == 0) {
+    DecState s;
+    s.n_active = 0; s.r_rows = 0; s.m_rows = 0; s.width = 1; s.steps = 0; s.error = 0; s.n_copy = 0; s.stop = 0;
+    s.accepted = s.produced = s.verified_positions = s.kv_prefix_positions = s.src_positions = 0;
+    *a.st = s;
+    a.host->width = 1; a.host->steps_done = 0; a.host->stop = 0; a.host->n_active = 0;
+    __threadfence_system();
+  }
+}
+
+struct PoolAdmitArgs {
+  DecState* st; int* act_idx; int* front; int* haspad; int* rstep; int* row_of; int* src_len; int* new_slot; HostInfo* host;
+  int B, N, D, R, first_row, Ls_new;
+};
+
+// One block.  Free slots = those not in act_idx[0, n_active); the R new rows take the lowest free ones in order.
+__global__ __launch_bounds__(256) void k_pool_admit(PoolAdmitArgs a) {
+  extern __shared__ int s_used[];                   // [B]
+  DecState* st = a.st;
+  const int n = st->n_active;
+  for (int i = threadIdx.x; i < a.B; i += blockDim.x) s_used[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s_used[a.act_idx[i]] = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int got = 0;
+    for (int b = 0; b < a.B && got < a.R; ++b) {
+      if (s_used[b]) continue;
+      a.new_slot[got] = b;
+      a.act_idx[n + got] = b;
+      a.front[b] = 0; a.haspad[b] = 0; a.rstep[b] = 0;
+      a.row_of[b] = a.first_row + got;
+      a.src_len[b] = a.Ls_new;
+      ++got;
+    }
+    // the host only admits as many rows as it knows to be free, so got == R
+    const int nn = n + got;
+    st->n_active = nn; st->r_rows = nn * a.N; st->m_rows = nn * step_rps(a.N, a.D);
+    st->stop = 0;
+    if (got != a.R) st->error = 4;
+    a.host->stop = 0;
+    a.host->n_active = nn;
+    __threadfence_system();
+  }
+}
+
+struct PoolFillArgs {
+  const int* new_slot; int R;
+  int* gen; int gen_ld; int bos; int pad;
+  int* drafts; const int* drafts_new; int nd;                         // N * D ints per row
+  uint8_t* src_valid; const uint8_t* valid_new; int Ls_cap; int Ls_new;
+  float* memkv; const float* memkv_new; int kv_row;                   // floats per source position (Ld * 2 * d)
+  int64_t* out_rows; short* traj_rows; int* fin_rows; int max_len; int traj_ld; int first_row;   // caller arrays of these rows
+};
+
+// grid (R, 1 + Ls_new): block (i, 0) initialises row i's slot scalars and its caller-side rows, block (i, 1 + key)
+// copies the cross K/V of one source position.
+__global__ __launch_bounds__(256) void k_pool_fill(PoolFillArgs a) {
+  const int i = blockIdx.x;
+  const int b = a.new_slot[i];
+  const int t = threadIdx.x;
+  if (blockIdx.y == 0) {
+    for (int c = t; c < a.gen_ld; c += blockDim.x) a.gen[(size_t)b * a.gen_ld + c] = (c == 0) ? a.bos : a.pad;
+    for (int c = t; c < a.nd; c += blockDim.x) a.drafts[(size_t)b * a.nd + c] = a.drafts_new[(size_t)i * a.nd + c];
+    for (int c = t; c < a.Ls_cap; c += blockDim.x)
+      a.src_valid[(size_t)b * a.Ls_cap + c] = (c < a.Ls_new) ? a.valid_new[(size_t)i * a.Ls_new + c] : (uint8_t)0;
+    const size_t row = (size_t)(a.first_row + i);
+    for (int c = t; c < a.max_len; c += blockDim.x) a.out_rows[row * a.max_len + c] = a.pad;
+    for (int c = t; c < a.traj_ld; c += blockDim.x) a.traj_rows[row * a.traj_ld + c] = (c == 0) ? 0 : -1;
+    if (t == 0) a.fin_rows[row] = 0;
+  } else {
+    const int key = blockIdx.y - 1;
+    const float4* src = reinterpret_cast<const float4*>(a.memkv_new + ((size_t)i * a.Ls_new + key) * a.kv_row);
+    float4* dst = reinterpret_cast<float4*>(a.memkv + ((size_t)b * a.Ls_cap + key) * a.kv_row);
+    for (int c = t; c < a.kv_row / 4; c += blockDim.x) dst[c] = src[c];
+  }
+}
+
+// Strided int64 -> int32 token copy + validity bytes for a chunk of rows of a wider matrix.
+__global__ void k_prepare_tokens_2d(const int64_t* in, int ld_in, int* out, uint8_t* valid, int rows, int cols, int pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * cols) {
+    const int r = i / cols, c = i - r * cols;
+    const int tk = (int)in[(size_t)r * ld_in + c];
+    out[i] = tk;
+    valid[i] = (tk != pad) ? 1 : 0;
   }
 }
 

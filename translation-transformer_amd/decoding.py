@@ -80,7 +80,7 @@ class TranslationInferenceGreedySpeculative:
         return out
 
     def generate_many(self, batches: list, in_flight: int = 4, reorder: bool = False, group_size: int | None = None,
-                      on_error: str = "raise") -> list:
+                      on_error: str = "raise", pool: bool | None = None) -> list:
         """Decode several batches with up to `in_flight` of them on the GPU at once (one session + stream each;
         ttx_greedy_speculative_generate_many).  Returns one [B,1,max_len] tensor per batch, each identical to what
         ``generate`` returns for that batch; counters accumulate as if ``generate`` had been called per batch.
@@ -101,7 +101,9 @@ class TranslationInferenceGreedySpeculative:
             return []
         if reorder:
             try:
-                return self._generate_reordered(batches, in_flight, group_size, on_error)
+                if pool is None:
+                    pool = os.environ.get("TTX_ROW_POOL", "1") != "0"
+                return self._generate_reordered(batches, in_flight, group_size, on_error, pool)
             except N.TtxError as e:
                 if e.code != N.TTX_ERR_ROW_REPLAY:
                     raise            # otherwise: a PAD inside a sequence; decode the batches as given
@@ -136,7 +138,8 @@ class TranslationInferenceGreedySpeculative:
             t["batches"] += 1
         return outs
 
-    def _generate_reordered(self, batches: list, in_flight: int, group_size: int | None, on_error: str = "raise") -> list:
+    def _generate_reordered(self, batches: list, in_flight: int, group_size: int | None, on_error: str = "raise",
+                            pool: bool = True) -> list:
         from .scheduling import plan_row_groups, replay_batch
         m = self.model
         L, T = self.max_len, self.max_len + 1
@@ -145,7 +148,10 @@ class TranslationInferenceGreedySpeculative:
         R = sum(sizes)
         # device group size: the given batch size is not binding any more; larger groups run the GEMMs at better MFMA
         # occupancy, but at least `in_flight` groups should exist so that tails overlap
-        gsz = int(group_size or min(256, max(max(sizes), -(-R // max(1, in_flight)))))
+        if pool:      # slot pool: about 2 048 slots in flight in total (512 x 4 measured best)
+            gsz = int(group_size or 512)
+        else:
+            gsz = int(group_size or min(256, max(max(sizes), -(-R // max(1, in_flight)))))
         self.last_group_size = gsz
         # all rows in one right-padded matrix; a row's length is the position after its last non-PAD token
         Lmax = max(int(s.shape[1]) for s in srcs)
@@ -160,23 +166,39 @@ class TranslationInferenceGreedySpeculative:
         order_t = torch.from_numpy(order).to(m.device)
         sorted_src = allsrc[order_t]
         sorted_len = lengths[order_t].cpu().numpy()
-        gsrc = [sorted_src[g, :max(2, int(sorted_len[g].max()))].contiguous() for g in groups]
-        n = len(gsrc)
         out_sorted = torch.empty((R, L), dtype=torch.int64, device=m.device)
         traj_sorted = torch.empty((R, T), dtype=torch.int16, device=m.device)
         fin_sorted = torch.empty((R,), dtype=torch.int32, device=m.device)
-        pool = m.session_pool(max(1, min(in_flight, n)))
-        sess = (C.c_void_p * len(pool))(*[p.value for p in pool])
-        src_p = (C.c_void_p * n)(*[s.data_ptr() for s in gsrc])
-        out_p = (C.c_void_p * n)(*[out_sorted[g].data_ptr() for g in groups])
-        traj_p = (C.c_void_p * n)(*[traj_sorted[g].data_ptr() for g in groups])
-        fin_p = (C.c_void_p * n)(*[fin_sorted[g].data_ptr() for g in groups])
-        Bs = (C.c_int * n)(*[s.shape[0] for s in gsrc])
-        Ls = (C.c_int * n)(*[s.shape[1] for s in gsrc])
         p = N.GenParams(L, self.draft_len, self.n_drafts, self.pad_token, self.bos_token, self.eos_token, self.replace_token, 0)
-        stats = (N.GenStats * n)()
-        N.check(m._lib.ttx_greedy_speculative_generate_rows(sess, len(pool), n, src_p, Bs, Ls, C.byref(p), out_p, traj_p, fin_p,
-                                                            stats, m._stream()))
+        if pool:
+            # continuous batching: every session keeps `gsz` slots filled from the sorted work list
+            # (ttx_greedy_speculative_generate_pool)
+            n_sess = max(1, min(in_flight, max(1, 2048 // gsz), -(-R // max(1, gsz // 2))))
+            sessions = m.session_pool(n_sess)
+            sess = (C.c_void_p * len(sessions))(*[q.value for q in sessions])
+            width = max(2, int(sorted_len[0]))
+            src_mat = sorted_src[:, :width].contiguous() if width <= sorted_src.shape[1] else torch.nn.functional.pad(
+                sorted_src, (0, width - sorted_src.shape[1]), value=self.pad_token).contiguous()
+            h_len = (C.c_int32 * R)(*[int(x) for x in sorted_len])
+            one = N.GenStats()
+            N.check(m._lib.ttx_greedy_speculative_generate_pool(sess, len(sessions), src_mat.data_ptr(), R, width, h_len, gsz,
+                                                                C.byref(p), out_sorted.data_ptr(), traj_sorted.data_ptr(),
+                                                                fin_sorted.data_ptr(), C.byref(one), m._stream()))
+            stats, gsrc = [one], [src_mat]
+        else:
+            gsrc = [sorted_src[g, :max(2, int(sorted_len[g].max()))].contiguous() for g in groups]
+            n = len(gsrc)
+            sessions = m.session_pool(max(1, min(in_flight, n)))
+            sess = (C.c_void_p * len(sessions))(*[q.value for q in sessions])
+            src_p = (C.c_void_p * n)(*[s.data_ptr() for s in gsrc])
+            out_p = (C.c_void_p * n)(*[out_sorted[g].data_ptr() for g in groups])
+            traj_p = (C.c_void_p * n)(*[traj_sorted[g].data_ptr() for g in groups])
+            fin_p = (C.c_void_p * n)(*[fin_sorted[g].data_ptr() for g in groups])
+            Bs = (C.c_int * n)(*[s.shape[0] for s in gsrc])
+            Ls = (C.c_int * n)(*[s.shape[1] for s in gsrc])
+            stats = (N.GenStats * n)()
+            N.check(m._lib.ttx_greedy_speculative_generate_rows(sess, len(sessions), n, src_p, Bs, Ls, C.byref(p), out_p, traj_p, fin_p,
+                                                                stats, m._stream()))
         # back to the caller's row order, then the reference's per-batch loop over the traces
         inv = torch.empty_like(order_t)
         inv[order_t] = torch.arange(R, device=m.device)
@@ -216,7 +238,7 @@ class TranslationInferenceGreedySpeculative:
             for k in ("model_calls", "accepted_tokens", "produced_tokens", "verified_positions", "kv_prefix_positions",
                       "src_positions"):
                 dv[k] += int(getattr(st, k))
-            dv["src_tokens_padded"] += int(gs.numel())
+            dv["src_tokens_padded"] += int(st.src_tokens_padded) if pool else int(gs.numel())
             dv["batches"] += 1
         t["device_model_calls"] = dv["model_calls"]
         if failed is not None:
