@@ -1587,14 +1587,15 @@ __global__ void k_loop_init(LoopArgs a) {
 // One block.  Verify each draft against the argmax tokens, keep the longest accepted prefix plus one
 // bonus token, retire rows that produced EOS, compact the active list, decide whether the loop goes on.
 __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
-  __shared__ int s_maxfront, s_anyfin, s_suspect, s_nn, s_maxf_new;
+  __shared__ int s_maxfront, s_anyfin, s_suspect, s_nn, s_maxf_new, s_nfin;
+  __shared__ int s_finlist[256];                    // finished rows of this step (their output copy is shared out below)
   __shared__ long long s_acc, s_prefix;
   __shared__ int s_scan[256];
   DecState* st = a.st;
   const int Bc = st->n_active;
   if (Bc == 0) return;
   const int D1 = a.D + 1, RPS = step_rps(a.N, a.D);
-  if (threadIdx.x == 0) { s_maxfront = 0; s_anyfin = 0; s_acc = 0; s_prefix = 0; s_suspect = 0; s_nn = 0; s_maxf_new = 0; }
+  if (threadIdx.x == 0) { s_maxfront = 0; s_anyfin = 0; s_acc = 0; s_prefix = 0; s_suspect = 0; s_nn = 0; s_maxf_new = 0; s_nfin = 0; }
   __syncthreads();
   for (int slot = threadIdx.x; slot < Bc; slot += blockDim.x) {
     const int b = a.act_idx[slot];
@@ -1605,8 +1606,11 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     for (int n = 0; n < a.N; ++n) {
       const int* dr = a.drafts + ((size_t)b * a.N + n) * a.D;
       const int* pr = ps + 1 + n * a.D - 1;            // pr[j] = prediction at position f + j for j >= 1
-      int acc = 0;
-      while (acc < a.D && dr[acc] == (acc == 0 ? ps[0] : pr[acc])) ++acc;
+      // first mismatch without an early exit: the D + D loads are independent and go out back to back (the
+      // early-exit loop was a chain of dependent global loads, ~30 round trips per row)
+      int acc = a.D;
+      for (int j = a.D - 1; j >= 0; --j)
+        if (dr[j] != (j == 0 ? ps[0] : pr[j])) acc = j;
       if (acc > bacc) { bacc = acc; best = n; }
     }
     const int* pr = ps + 1 + best * a.D - 1;
@@ -1640,7 +1644,11 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     atomicMax(&s_maxfront, f);
     atomicAdd((unsigned long long*)&s_acc, (unsigned long long)bacc);
     atomicAdd((unsigned long long*)&s_prefix, (unsigned long long)f);
-    if (fin) s_anyfin = 1;
+    if (fin) {
+      s_anyfin = 1;
+      const int k = atomicAdd(&s_nfin, 1);
+      if (k < 256) s_finlist[k] = b;
+    }
   }
   __syncthreads();
   const int width = s_maxfront + 1 + D1;          // columns of generated_tokens after this step (:97-102,:145)
@@ -1668,13 +1676,16 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     __syncthreads();
   }
   const int wout = a.row_rule ? a.max_len : wcopy;    // columns past a row's front are PAD either way
-  for (int slot = 0; slot < Bc; ++slot) {
-    if (a.rec[slot].flags == 1) {                   // uniform over the block
-      const int b = a.rec[slot].b;
-      const int* g = a.gen + (size_t)b * a.gen_ld;
-      int64_t* orow = a.pool ? a.io->out + (size_t)a.row_of[b] * a.max_len : a.out + (size_t)b * a.max_len;
-      for (int c = threadIdx.x; c < wout; c += blockDim.x) orow[c] = g[c];
-    }
+  auto copy_row = [&](int b, int first, int stride) {
+    const int* g = a.gen + (size_t)b * a.gen_ld;
+    int64_t* orow = a.pool ? a.io->out + (size_t)a.row_of[b] * a.max_len : a.out + (size_t)b * a.max_len;
+    for (int c = first; c < wout; c += stride) orow[c] = g[c];
+  };
+  if (s_nfin <= 256) {                               // one wave per finished row
+    for (int k = threadIdx.x >> 6; k < s_nfin; k += 4) copy_row(s_finlist[k], threadIdx.x & 63, 64);
+  } else {                                           // more rows finished at once than the list holds: scan all slots
+    for (int slot = 0; slot < Bc; ++slot)
+      if (a.rec[slot].flags == 1) copy_row(a.rec[slot].b, threadIdx.x, blockDim.x);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
