@@ -298,6 +298,7 @@ struct ttx_session {
   bool profile = false;
   bool gemm_v1 = false, attn_v1 = false, attn_v3 = true;
   int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
+  int fuse_ln_min_rows = 0;        // d-wide GEMM + LayerNorm fused (k_gemm_ln256) from this row capacity on; 0: never (slower)
   int big_min_tiles = 192;         // 128x128 tiling once it yields this many workgroups (k_gemm24); 0: never
   int proj_split = 1;              // largest split-K factor of the step's d x d projections on the 64x64 kernel
   int gemm3_max_n = 0;             // step GEMMs at most this wide use the 32x32 kernel (k_gemm3); 0: none
@@ -378,6 +379,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   if (const char* f2 = getenv("TTX_FFN2_SPLIT")) s->ffn2_split = std::max(1, atoi(f2));
   if (const char* ps = getenv("TTX_PROJ_SPLIT")) s->proj_split = std::max(1, atoi(ps));
   if (const char* a3 = getenv("TTX_ATTN_V3")) s->attn_v3 = atoi(a3) != 0;
+  if (const char* fl = getenv("TTX_FUSE_LN_MIN_ROWS")) s->fuse_ln_min_rows = std::max(0, atoi(fl));
   if (const char* bt = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(bt));
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
@@ -564,6 +566,29 @@ static int gemm_ln(ttx_session* s, hipStream_t st, const float* X, int ldx, int 
                    const uint8_t* row_valid, float* Y, const int* m_ptr, int Mmax) {
   const int d = s->m->cfg.embedding_dim;
   const int S = choose_splits(s, m_ptr != nullptr, d, K);
+  if (m_ptr && S == 1 && d == 256 && K % 64 == 0 && s->fuse_ln_min_rows > 0 && Mmax >= s->fuse_ln_min_rows && !s->gemm_v1) {
+    // enough row capacity for 64-row workgroups to fill the chip: GEMM + finish in one launch (bit-identical result)
+    GemmLnArgs a{};
+    a.g.X = X; a.g.ldx = ldx; a.g.W = W; a.g.ldw = K; a.g.m_ptr = m_ptr; a.g.M = Mmax; a.g.N = d; a.g.K = K;
+    a.f.bias = bias; a.f.resid = resid; a.f.g1 = g1; a.f.b1 = b1; a.f.g2 = g2; a.f.b2 = b2; a.f.row_valid = row_valid; a.f.Y = Y;
+    a.f.m_ptr = m_ptr; a.f.M = Mmax; a.f.d = d; a.f.eps = s->m->cfg.layer_norm_eps;
+    hipEvent_t e1 = nullptr;
+    if (s->profile) {
+      if (s->ev_used == s->ev_pool.size()) {
+        hipEvent_t a0, a1;
+        HIP_TRY(hipEventCreate(&a0));
+        HIP_TRY(hipEventCreate(&a1));
+        s->ev_pool.push_back({a0, a1});
+      }
+      HIP_TRY(hipEventRecord(s->ev_pool[s->ev_used].first, st));
+      e1 = s->ev_pool[s->ev_used].second;
+      s->ev_used++;
+    }
+    hipLaunchKernelGGL(k_gemm_ln256, dim3(cdiv(Mmax, 64)), dim3(256), 0, st, a);
+    if (e1) HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipGetLastError());
+    return TTX_OK;
+  }
   const long long stride = (long long)Mmax * d;
   TTX_TRY(ensure(s->slab, sizeof(float) * (size_t)S * stride, st));
   TTX_TRY(launch_gemm(s, st, X, ldx, W, K, nullptr, s->slab.as<float>(), d, m_ptr, Mmax, d, K, false, S, stride));
@@ -1403,7 +1428,9 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
     HIP_TRY(hipStreamWaitEvent(s->own_stream, ready, 0));
     rc_final = pool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, d_out, d_traj, d_fin_step);
   }
-  const int min_admit = std::max(1, C / 4);
+  int admit_div = 4;
+  if (const char* e = getenv("TTX_POOL_ADMIT_DIV")) admit_div = std::max(1, atoi(e));
+  const int min_admit = std::max(1, C / admit_div);
   int cursor = 0, done = 0;
   while (done < n_jobs && rc_final == TTX_OK) {
     bool progressed = false;

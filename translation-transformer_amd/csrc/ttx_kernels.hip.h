@@ -1230,6 +1230,140 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
+// GEMM + bias + residual + LayerNorm in one launch for the d-wide projections of the verify step at large row counts
+// (d = 256): a workgroup owns 64 FULL rows (4 waves side by side, each 64 rows x 64 columns = the four-accumulator
+// wave tile of k_gemm4, same two-tiles-in-flight pipeline), parks the raw products in LDS and then finishes its rows
+// exactly the way k_finish_ln does — one wave per row, lane c owns columns 4c..4c+3, x = (resid + bias) + product,
+// same shuffle reductions — so the result is bit-identical to k_gemm2 / k_gemm4 (one slab) followed by k_finish_ln,
+// and the choice between the two may follow the launch's row capacity.  Saves the finish launch and the 2 x M x d x 4
+// bytes of slab traffic.
+struct GemmLnArgs {
+  GemmArgs g;                 // X, W, K, m_ptr, M (row capacity), N = d; bias/Y/raw unused
+  FinishArgs f;               // bias, resid, g1/b1 (, g2/b2), row_valid, Y, d, eps; slabs unused
+};
+
+__global__ __launch_bounds__(256) void k_gemm_ln256(GemmLnArgs args) {
+  // 16-deep K tiles: the double-buffered operand images (50 KB) stay below the row image (66.5 KB), so two workgroups
+  // share a CU (with 32-deep tiles it was one per CU and 46 us per launch against 24 + 14 for the separate kernels)
+  constexpr int BM = 64, BN = 256, BK = 16, LDT = BK + 4, LDX = BN + 4;
+  constexpr int OPER = 2 * BM * LDT + 2 * BN * LDT, IMG = BM * LDX;
+  __shared__ __attribute__((aligned(16))) float smem[OPER > IMG ? OPER : IMG];
+  const GemmArgs& a = args.g;
+  const FinishArgs& fa = args.f;
+  float (*As)[BM * LDT] = reinterpret_cast<float (*)[BM * LDT]>(smem);
+  float (*Bs)[BN * LDT] = reinterpret_cast<float (*)[BN * LDT]>(smem + 2 * BM * LDT);
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  const int m0 = blockIdx.x * BM;
+  if (m0 >= M) return;
+  const int ntiles = a.K / BK;
+  const int t = threadIdx.x;
+  const int lr = t >> 2, lc = (t & 3) * 4;       // 4 float4 per 16-float row, 64 rows per pass
+  const int wave = t >> 6, lane = t & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const float* xp = a.X + (size_t)min(m0 + lr, M - 1) * a.ldx + lc;
+  const float* wp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wp[i] = a.W + (size_t)(lr + 64 * i) * a.ldw + lc;
+  struct Frag { float4 a0, b0, b1, b2, b3; };
+  auto gload = [&](int tile) {
+    Frag f;
+    const int ko = tile * BK;
+    f.a0 = *reinterpret_cast<const float4*>(xp + ko);
+    f.b0 = *reinterpret_cast<const float4*>(wp[0] + ko);
+    f.b1 = *reinterpret_cast<const float4*>(wp[1] + ko);
+    f.b2 = *reinterpret_cast<const float4*>(wp[2] + ko);
+    f.b3 = *reinterpret_cast<const float4*>(wp[3] + ko);
+    return f;
+  };
+  auto lstore = [&](const Frag& f, int buf) {
+    float* as = As[buf] + lr * LDT + lc;
+    float* bs = Bs[buf] + lr * LDT + lc;
+    *reinterpret_cast<float4*>(as) = f.a0;
+    *reinterpret_cast<float4*>(bs) = f.b0;
+    *reinterpret_cast<float4*>(bs + 64 * LDT) = f.b1;
+    *reinterpret_cast<float4*>(bs + 128 * LDT) = f.b2;
+    *reinterpret_cast<float4*>(bs + 192 * LDT) = f.b3;
+  };
+  f32x16 c00, c01, c10, c11;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; }
+  const int aoff = r * LDT + 4 * h, boff = (wave * 64 + r) * LDT + 4 * h;
+  auto mma = [&](int buf) {
+    const float* ap = As[buf] + aoff;
+    const float* bp = Bs[buf] + boff;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ap + kk);
+      const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDT + kk);
+      const float4 b0 = *reinterpret_cast<const float4*>(bp + kk);
+      const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDT + kk);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, c11, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, c11, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, c11, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, c11, 0, 0, 0);
+    }
+  };
+  const int last = ntiles - 1;
+  Frag f0 = gload(0);
+  asm volatile("" ::: "memory");
+  Frag f1 = gload(min(1, last));
+  for (int i = 0; i < ntiles; i += 2) {           // K is a multiple of 32: ntiles is even
+    lstore(f0, 0);
+    asm volatile("" ::: "memory");
+    f0 = gload(min(i + 2, last));
+    __syncthreads();
+    mma(0);
+    lstore(f1, 1);
+    asm volatile("" ::: "memory");
+    f1 = gload(min(i + 3, last));
+    __syncthreads();
+    mma(1);
+  }
+  __syncthreads();                                 // everybody is done with the operand buffers: reuse them as the row image
+  float* T = smem;                                 // [64][LDX]
+  auto park = [&](const f32x16& c, int tm, int tn) {
+    const int col = wave * 64 + tn * 32 + r;
+    const int row0 = tm * 32 + 4 * h;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) T[(row0 + (v & 3) + 8 * (v >> 2)) * LDX + col] = c[v];
+  };
+  park(c00, 0, 0);
+  park(c01, 0, 1);
+  park(c10, 1, 0);
+  park(c11, 1, 1);
+  __syncthreads();
+  // the k_finish_ln<4> arithmetic, 16 rows per wave
+  const int c0 = lane * 4;
+  const float4 bias4 = *reinterpret_cast<const float4*>(fa.bias + c0);
+  for (int rr = wave; rr < BM; rr += 4) {
+    const int row = m0 + rr;
+    if (row >= M) break;
+    const size_t off = (size_t)row * fa.d + c0;
+    const float4 rs = *reinterpret_cast<const float4*>(fa.resid + off);
+    const float4 pv = *reinterpret_cast<const float4*>(T + rr * LDX + c0);
+    float x[4] = {rs.x + bias4.x, rs.y + bias4.y, rs.z + bias4.z, rs.w + bias4.w};
+    x[0] += pv.x; x[1] += pv.y; x[2] += pv.z; x[3] += pv.w;
+    ln_inplace<4>(x, fa.g1, fa.b1, c0, fa.d, fa.eps);
+    if (fa.g2) ln_inplace<4>(x, fa.g2, fa.b2, c0, fa.d, fa.eps);
+    const bool keep = fa.row_valid ? (fa.row_valid[row] != 0) : true;
+    float4 y = {keep ? x[0] : 0.f, keep ? x[1] : 0.f, keep ? x[2] : 0.f, keep ? x[3] : 0.f};
+    *reinterpret_cast<float4*>(fa.Y + off) = y;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Attention v3 for the verify step: ONE WAVE per (running sequence, head, 32 step rows), no LDS, no barrier.
 //
 // Everything stays in the layout the fp32 MFMA produces.  Scores are computed TRANSPOSED, S^T = K Q^T (A operand =
