@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TTX_ABI_VERSION 1
+#define TTX_ABI_VERSION 2
 
 typedef enum ttx_status {
   TTX_OK = 0,

@@ -139,7 +139,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if handle.ttx_abi_version() != 1:
+    if handle.ttx_abi_version() != 2:
         raise RuntimeError("libttx_hip.so ABI version mismatch")
     _lib = handle
     return _lib

@@ -297,6 +297,7 @@ struct ttx_session {
   // profiling of the GEMM launches (bench.py roofline)
   bool profile = false;
   bool gemm_v1 = false, attn_v1 = false, attn_v3 = true;
+  bool tree_big_policy = false;    // TTX_TREE_BIG_POLICY=1: beam paths under the large-row-count GEMM policy too
   int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
   int fuse_ln_min_rows = 0;        // d-wide GEMM + LayerNorm fused (k_gemm_ln256) from this row capacity on; 0: never (slower)
   int big_min_tiles = 192;         // 128x128 tiling once it yields this many workgroups (k_gemm24); 0: never
@@ -379,6 +380,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   if (const char* f2 = getenv("TTX_FFN2_SPLIT")) s->ffn2_split = std::max(1, atoi(f2));
   if (const char* ps = getenv("TTX_PROJ_SPLIT")) s->proj_split = std::max(1, atoi(ps));
   if (const char* a3 = getenv("TTX_ATTN_V3")) s->attn_v3 = atoi(a3) != 0;
+  if (const char* tb = getenv("TTX_TREE_BIG_POLICY")) s->tree_big_policy = atoi(tb) != 0;
   if (const char* fl = getenv("TTX_FUSE_LN_MIN_ROWS")) s->fuse_ln_min_rows = std::max(0, atoi(fl));
   if (const char* bt = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(bt));
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
@@ -1670,7 +1672,19 @@ extern "C" int ttx_tree_step(ttx_session* s, const int64_t* d_cand, int n_cand, 
   k.B = t.max_cand; k.Ls = t.Ls; k.N = N; k.D = D; k.Lc = t.Lc; k.gen_ld = t.gen_ld; k.max_len = t.max_len;
   k.kcache = s->tk[t.cur].as<float>(); k.vcache = s->tv[t.cur].as<float>(); k.src_of = d_src_row; k.want_argmax = false;
   // NOTE: the step kernels lay their rows out with stride max_cand * RPS(N, D) per layer in s->qkv
-  TTX_TRY(run_step(s, st, k, std::min(t.max_len, ((width + 63) / 64) * 64)));
+  {
+    // The beam paths verify a few hundred rows per step: they run under the small-batch kernel policy (32x32 K-split
+    // kernel for the narrow GEMMs, deeper split-K — §4.2 of DESIGN.md).  The greedy paths keep one policy for every
+    // row count so that their outputs are bit-identical across groupings; the beam paths never mix with them.
+    struct PolicyScope {
+      ttx_session* s; int g3, ps, fs, bt;
+      explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles) {
+        if (!s->tree_big_policy) { s->gemm3_max_n = 768; s->proj_split = 4; s->ffn2_split = 8; s->big_min_tiles = 0; }
+      }
+      ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; }
+    } scope(s);
+    TTX_TRY(run_step(s, st, k, std::min(t.max_len, ((width + 63) / 64) * 64)));
+  }
   // 4. logits of the step rows -> [n_cand, N, D+1, V]
   hipLaunchKernelGGL(k_tree_logits, dim3(n_cand, N * (D + 1)), dim3(256), 0, st, s->logits.as<float>(), V, s->state.as<DecState>(),
                      s->act_idx.as<int>(), N, D, d_logits);
