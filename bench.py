@@ -110,7 +110,11 @@ def flops_and_bytes(cfg: dict, stats: dict, B_total_src_tokens: int, n_batches: 
     kv_read = (stats["kv_prefix_positions"] + stats["src_positions"]) * 2 * d * 4 * Ld
     kv_write = stats["produced_tokens"] * 2 * d * 4 * Ld
     bytes_total = n_batches * W_enc + steps * W_dec + kv_read + kv_write
-    return {"gemm_flops": float(gemm_flops), "bytes": float(bytes_total)}
+    # operand bytes of the GEMM launches alone (activations in + out per position / source token, weights per pass)
+    dec_io = 4 * (Ld * ((d + 3 * d) + 3 * (d + d) + (d + F) + (F + 2 * d)) + (d + V))
+    enc_io = 4 * (Le * ((d + 3 * d) + (d + d) + (d + F) + (F + d)) + (d + Ld * 2 * d))
+    gemm_bytes = pos * dec_io + B_total_src_tokens * enc_io + steps * W_dec + n_batches * (W_enc + 4 * Ld * 2 * d * d)
+    return {"gemm_flops": float(gemm_flops), "bytes": float(bytes_total), "gemm_bytes": float(gemm_bytes)}
 
 
 def main():
@@ -300,10 +304,20 @@ def main():
                 pstats = dict(pstats["device"], encode_ms=pstats["encode_ms"], decode_ms=pstats["decode_ms"])
             pw = flops_and_bytes(cfg, pstats, pstats["src_tokens_padded"], pstats.get("batches", len(timed)))
             ach = pw["gemm_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            pmc = {}
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_pmc_traffic.json")) as fh:
+                    pmc = json.load(fh)
+            except OSError:
+                pass
             line["roofline"] = {"kernel": "k_gemm2 (fp32 v_mfma_f32_32x32x2_f32 GEMMs, every launch of the run: encoder, cross K/V, verify steps)",
                                 "bound": "mfma", "achieved": ach,
                                 "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
-                                "traffic": None, "launches": launches, "avg_launch_us": 1e3 * raw_ms / max(1, launches),
+                                "traffic": pmc.get("bytes_per_launch"), "launches": launches,
+                                "traffic_note": ("HBM-side bytes per GEMM launch (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included) "
+                                                 "from the committed rocprofv3 --pmc passes of this command: profiles/r01_gemm_pmc_traffic.json")
+                                                if pmc else "no PMC file",
+                                "algorithmic_bytes_per_launch": pw["gemm_bytes"] / max(1, launches), "avg_launch_us": 1e3 * raw_ms / max(1, launches),
                                 "note": "achieved/avg_launch_us use the raw event-pair time (conservative: an empty pair alone "
                                         "measures event_pair_overhead_us; rocprofv3 kernel-trace averages are in profiles/)",
                                 "event_pair_overhead_us": 1e3 * empty_ms,
