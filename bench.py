@@ -37,14 +37,14 @@ BASELINE_REACTIONS_PER_S = 47.97  # BASELINE.md §1, bs=32 D=10 N=3 (reference's
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--draft-len", type=int, default=10)
     ap.add_argument("--n-drafts", type=int, default=3)
     ap.add_argument("--max-len", type=int, default=200)
     ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "1500")))
-    ap.add_argument("--cpu-batches", type=int, default=1, help="batches of the workload timed on the host cores")
+    ap.add_argument("--cpu-batches", type=int, default=3, help="batches of the workload timed on the host cores")
     ap.add_argument("--schedule", choices=("rows", "batches"), default=os.environ.get("TTX_SCHEDULE", "rows"),
                     help="rows: regroup the rows of the given batches by length (exact replay per batch); batches: as given")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("TTX_INFLIGHT", "8")),
