@@ -196,3 +196,50 @@ def test_kv_cached_step_logits_match_full_prefix_oracle(tta, full_pair):
                 assert np.array_equal(got.argmax(-1), ref.numpy().argmax(-1))
     print("KV-cached verify-step logits vs full-prefix oracle: max abs diff", worst)
     assert worst < 1e-3
+
+
+def test_full_size_row_schedule_pool_equals_per_batch_and_oracle(tta, full_pair):
+    """The slot-pool row schedule on the real layer sizes with hundreds of rows in flight (128x128 GEMM tiling,
+    attention v3, admissions while other rows run): every given batch equals per-batch `generate`, and the first
+    batches equal the oracle."""
+    from oracle.decoding import GreedySpeculativeOracle
+    native, oracle = full_pair
+    src, _, c, _ = fixture_tokens()
+    rows = []
+    for i in range(src.shape[0]):
+        n = int((src[i] != PAD).sum())
+        for cut in range(8, n - 1, max(1, (n - 9) // 40)):
+            r = src[i, :cut].clone()
+            r[cut - 1] = EOS
+            rows.append(r)
+    W = max(len(r) for r in rows)
+    mat = torch.full((len(rows), W), PAD, dtype=torch.int64)
+    for k, r in enumerate(rows):
+        mat[k, :len(r)] = r
+    perm = torch.randperm(len(rows), generator=torch.Generator().manual_seed(5))
+    mat = mat[perm]
+    batches = [mat[i:i + 32] for i in range(0, len(rows), 32)]
+    batches = [b[:, :int((b != PAD).sum(1).max())].cuda() for b in batches]
+    ref, raised = [], 0
+    g1 = tta.TranslationInferenceGreedySpeculative(native, 200, 10, 3, PAD, BOS, EOS, c)
+    for b in batches:
+        try:
+            ref.append(g1.generate(b))
+        except tta.ReferenceError_:
+            ref.append(None)
+            raised += 1
+    g2 = tta.TranslationInferenceGreedySpeculative(native, 200, 10, 3, PAD, BOS, EOS, c)
+    out = g2.generate_many(batches, in_flight=4, reorder=True, on_error="skip")
+    for i, (a, b) in enumerate(zip(out, ref)):
+        assert (a is None) == (b is None), i
+        if a is not None:
+            assert torch.equal(a, b), i
+    assert g2.model_calls_num == g1.model_calls_num
+    used_pool = "device" in g2.stats_total
+    print(f"{len(rows)} rows in {len(batches)} batches, {raised} raise like the reference; row schedule ran: {used_pool}",
+          g2.stats_total.get("device", {}).get("model_calls"), "device steps for", g2.model_calls_num, "replayed calls")
+    for i in range(2):
+        if ref[i] is None:
+            continue
+        exp = GreedySpeculativeOracle(oracle, 200, 10, 3, PAD, BOS, EOS, c).generate(batches[i].cpu())
+        assert torch.equal(out[i].cpu(), exp), i
