@@ -1381,9 +1381,11 @@ struct A3Tile {
   int own;                   // validity word of key key0 + r (token / source-valid byte), balloted below
 };
 
+// `n_plain` = number of leading keys that every query sees whenever they are real tokens (cached prefix and front
+// token, or all encoder positions): tiles made of such keys skip the per-key flag arithmetic altogether.
 template <int MODE, typename KeyPtr, typename KeyOwn, typename KeyFlag, typename QFlag>
-__device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int nk, KeyPtr keyptr, KeyOwn keyown, KeyFlag keyflag,
-                                           QFlag qflag, float* out, int ldo, float scale) {
+__device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int nk, int n_plain, KeyPtr keyptr, KeyOwn keyown,
+                                           KeyFlag keyflag, QFlag qflag, float* out, int ldo, float scale) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   // B operand of S^T: query r, dims 8g + 4h .. +3 (rows past nq repeat the last query; they are never stored)
@@ -1450,16 +1452,26 @@ __device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int 
     sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.y, qv[3].y, sacc, 0, 0, 0);
     sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.z, qv[3].z, sacc, 0, 0, 0);
     sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.w, qv[3].w, sacc, 0, 0, 0);
-    // validity of the tile's 32 keys as a bit mask (lanes 0..31 hold keys key0 .. key0+31)
-    const unsigned valid = (unsigned)__ballot(cur.own != 0);
+    // validity of the tile's 32 keys as a bit mask (lanes 0..31 hold keys key0 .. key0+31), keys past nk cleared
+    unsigned valid = (unsigned)__ballot(cur.own != 0);
+    if (nk - key0 < 32) valid &= (1u << (nk - key0)) - 1u;
     float mx = -INFINITY;
+    if (key0 + 32 <= n_plain) {                       // uniform: a tile of plain keys (most tiles)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int j = (t & 3) + 8 * (t >> 2) + 4 * h;
-      const int key = key0 + j;
-      const int kf = key < nk ? keyflag(key, (valid >> j) & 1u) : A2_MASKED;
-      sacc[t] = a2_visible(qf, kf) ? sacc[t] : -INFINITY;
-      mx = fmaxf(mx, sacc[t]);
+      for (int t = 0; t < 16; ++t) {
+        const int j = (t & 3) + 8 * (t >> 2) + 4 * h;
+        sacc[t] = ((valid >> j) & 1u) ? sacc[t] : -INFINITY;
+        mx = fmaxf(mx, sacc[t]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int j = (t & 3) + 8 * (t >> 2) + 4 * h;
+        const int kf = keyflag(min(key0 + j, nk - 1), (valid >> j) & 1u);     // keys past nk: valid bit 0 -> see below
+        const bool vis = (key0 + j < nk) && a2_visible(qf, kf);
+        sacc[t] = vis ? sacc[t] : -INFINITY;
+        mx = fmaxf(mx, sacc[t]);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m, mx);
@@ -1521,7 +1533,7 @@ __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
     const int n_hi = (rlast == 0) ? -1 : (rlast - 1) / D;
     const int kr0 = 1 + n_lo * D;
     const int n_draft_keys = (n_hi >= n_lo && D > 0) ? (n_hi - n_lo + 1) * D : 0;
-    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, f + 1 + n_draft_keys,
+    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, f + 1 + n_draft_keys, f + 1,
                      [=](int key, const float*& kp, const float*& vp) {
                        const bool cached = key < f;
                        const int srow = (key == f) ? 0 : kr0 + (key - f - 1);
@@ -1549,7 +1561,8 @@ __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
     const float* kb = a.k + mrow0 * a.ldkv + hd;
     const float* vb = a.v + mrow0 * a.ldkv + hd;
     const int ld = a.ldkv;
-    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, a.src_len ? a.src_len[b] : a.Lk,
+    const int nkeys = a.src_len ? a.src_len[b] : a.Lk;
+    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, nkeys, ((nkeys + 31) & ~31),
                      [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                      [=](int key) { return (int)kvalid[key]; },
                      [=](int, unsigned real) { return real ? A2_ALL : A2_MASKED; },
