@@ -1410,10 +1410,14 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
   if (R_total == 0) return TTX_OK;
   if (p->max_len > 32000) return fail(TTX_ERR_INVALID, "max_len too large for the int16 trace");
   // rows must come longest first: the first row fixes the slot width
-  int Ls_cap = std::max(2, (int)h_len[0]);
   for (int i = 1; i < R_total; ++i)
     if (h_len[i] > h_len[i - 1]) return fail(TTX_ERR_INVALID, "rows must be sorted by length, longest first");
-  if (Ls_cap > Ls_all) return fail(TTX_ERR_INVALID, "row length beyond the source matrix width");
+  if (h_len[0] > Ls_all) return fail(TTX_ERR_INVALID, "row length beyond the source matrix width");
+  // slot width: 192 positions, beyond that in steps of 64 — calls whose longest sources differ share workspaces and
+  // the captured step graph (a slot's keys are bounded by its own source length, so the padding costs memory only:
+  // 0.8 GB of cross K/V per 512-slot pool at 192)
+  int Ls_cap = std::min(std::max(192, (((int)h_len[0] + 63) / 64) * 64), sessions[0]->m->cfg.max_positions);
+  Ls_cap = std::max(Ls_cap, std::max(2, (int)h_len[0]));
   TTX_TRY(gen_validate(sessions[0], d_src, capacity, Ls_cap, p, d_out, false));
   HIP_TRY(hipSetDevice(sessions[0]->m->device));
   release_retired();

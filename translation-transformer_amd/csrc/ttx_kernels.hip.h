@@ -1431,8 +1431,10 @@ __device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int 
     const int key0 = it * 32;
     // the next tile's loads go out before this tile's arithmetic (the empty asm keeps them above it); the copy at the
     // bottom of the loop is where they are waited for
+#ifndef TTX_A3_NOPREFETCH
     A3Tile nxt = load_tile(min(it + 1, ntiles - 1) * 32);
     asm volatile("" ::: "memory");
+#endif
     f32x16 sacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
@@ -1490,7 +1492,11 @@ __device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int 
     for (int i = 0; i < 16; ++i) o[i] *= alpha;
 #pragma unroll
     for (int t = 0; t < 16; ++t) o = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[t], sacc[t], o, 0, 0, 0);
+#ifndef TTX_A3_NOPREFETCH
     cur = nxt;
+#else
+    if (it + 1 < ntiles) cur = load_tile((it + 1) * 32);
+#endif
   }
   // o[v] = O[query r][dim (v&3) + 8(v>>2) + 4h]: four float4 per lane
   if (r < nq) {
