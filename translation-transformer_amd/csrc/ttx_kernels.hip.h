@@ -537,7 +537,15 @@ __global__ __launch_bounds__(256) void k_gemm24(GemmArgs a) {
     const int nbx = (a.N + 127) >> 7, nby = (M + 127) >> 7;
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     if (lin >= big_tiles) return;
-    const int slice = lin / (nbx * nby), rem = lin - slice * (nbx * nby);
+#ifndef TTX_NO_XCD_REMAP
+    // XCD-aware order (speed only): workgroups lin and lin + 8 share an XCD and its L2, so the workgroups of one XCD
+    // take a CONTIGUOUS run of tiles — the column tiles of a row block (same X rows) then hit one L2 instead of eight.
+    const int xb = big_tiles >> 3, xr = big_tiles & 7, xcd = lin & 7;
+    const int v = xcd * xb + min(xcd, xr) + (lin >> 3);
+#else
+    const int v = lin;
+#endif
+    const int slice = v / (nbx * nby), rem = v - slice * (nbx * nby);
     g4_body(a, M, rem % nbx, rem / nbx, slice, smem);
   } else {
     g2_body<NT>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
