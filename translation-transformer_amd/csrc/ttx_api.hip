@@ -1598,6 +1598,7 @@ extern "C" int ttx_tree_begin(ttx_session* s, const int64_t* d_src, int B, int L
   const ttx_config& c = m->cfg;
   if (max_len + draft_len + 2 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len + draft_len exceeds the positional table");
   HIP_TRY(hipSetDevice(m->device));
+  release_retired();
   hipStream_t st = (hipStream_t)stream;
   const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
   auto& t = s->tree;

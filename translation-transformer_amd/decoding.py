@@ -141,6 +141,8 @@ class TranslationInferenceGreedySpeculative:
     def _generate_reordered(self, batches: list, in_flight: int, group_size: int | None, on_error: str = "raise",
                             pool: bool = True) -> list:
         from .scheduling import plan_row_groups, replay_batch
+        import time as _time
+        _t0 = _time.perf_counter()
         m = self.model
         L, T = self.max_len, self.max_len + 1
         srcs = [b.to(m.device, torch.int64) for b in batches]
@@ -199,6 +201,7 @@ class TranslationInferenceGreedySpeculative:
             stats = (N.GenStats * n)()
             N.check(m._lib.ttx_greedy_speculative_generate_rows(sess, len(sessions), n, src_p, Bs, Ls, C.byref(p), out_p, traj_p, fin_p,
                                                                 stats, m._stream()))
+        _t1 = _time.perf_counter()
         # back to the caller's row order, then the reference's per-batch loop over the traces
         inv = torch.empty_like(order_t)
         inv[order_t] = torch.arange(R, device=m.device)
@@ -245,6 +248,10 @@ class TranslationInferenceGreedySpeculative:
             raise N.ReferenceError_(f"batch {failed}: a row finished at a width beyond max_len: shape mismatch in the reference "
                                     "(speculative_decoding.py:158)")
         out_rows = torch.where(keep.to(m.device)[:, None], out_rows, torch.full_like(out_rows, self.pad_token))
+        if os.environ.get("TTX_HOST_PROFILE"):
+            torch.cuda.synchronize()
+            print(f"[ttx rows] prepare+device {1e3 * (_t1 - _t0):.1f} ms, replay+scatter {1e3 * (_time.perf_counter() - _t1):.1f} ms",
+                  flush=True)
         outs, r0 = [], 0
         skipped = set(self.last_failed_batches)
         for bi, B in enumerate(sizes):
