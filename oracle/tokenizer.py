@@ -5,7 +5,7 @@
   decode        <- GenericTokenizer.decode                    src/data_handling/tokenizer_base.py:80-91
 
 Pinned by tests/golden/tokenizer_cases.json (outputs of the reference tokenizer itself).  Also serves as the
-CPU baseline of tools/bench_tokenizer.py (kind "port": the same `re` engine and per-token dict lookups as the
+CPU baseline of tests/bench_tokenizer.py (kind "port": the same `re` engine and per-token dict lookups as the
 reference).
 """
 from __future__ import annotations
