@@ -219,3 +219,42 @@ def test_generate_many_skip_mode(tta, tiny):
             assert (o is None) == (i in bad)
             if o is not None:
                 assert torch.equal(o, ref[i])
+
+
+def test_slot_pool_randomised_partitions(tta, tiny):
+    """Random batch partitions, pool capacities, session counts and decoding parameters: the row schedule (slot pool and
+    fixed groups) returns, batch by batch, what per-batch `generate` returns — including which batches raise."""
+    src, _, c, _ = fixture_tokens()
+    rng = np.random.default_rng(42)
+    checked = fell_back = 0
+    for trial in range(12):
+        max_len = int(rng.choice([150, 60, 45, 33, 27]))
+        D = int(rng.choice([3, 4, 6, 10]))
+        N = int(rng.choice([1, 2, 3, 5]))
+        if D > max_len:
+            continue
+        # rows: fixture sources, some repeated, in random order, cut into random batches
+        idx = rng.integers(0, src.shape[0], size=int(rng.integers(5, 40)))
+        cuts = sorted(set(rng.integers(1, len(idx), size=int(rng.integers(1, 6))).tolist()))
+        parts = np.split(idx, cuts)
+        batches = []
+        for p in parts:
+            sel = src[torch.from_numpy(p)]
+            batches.append(sel[:, :int((sel != PAD).sum(1).max())].cuda())
+        ref, calls = _sequential(tta, tiny, batches, max_len, D, N, c)
+        bad = [i for i, o in enumerate(ref) if o is None]
+        for pool in (True, False):
+            g = tta.TranslationInferenceGreedySpeculative(tiny, max_len, D, N, PAD, BOS, EOS, c)
+            out = g.generate_many(batches, in_flight=int(rng.integers(1, 6)), reorder=True, group_size=int(rng.integers(1, 48)),
+                                  on_error="skip", pool=pool)
+            fell_back += "device" not in g.stats_total
+            assert sorted(g.last_failed_batches) == bad, (trial, pool)
+            for i, o in enumerate(out):
+                if i in bad:
+                    assert o is None
+                else:
+                    assert torch.equal(o, ref[i]), (trial, pool, i)
+            assert g.model_calls_num == sum(calls[i] for i in range(len(batches)) if i not in bad)
+            checked += 1
+    print(f"{checked} randomised schedules checked, {fell_back} fell back to decoding as given")
+    assert checked >= 16 and fell_back == 0
