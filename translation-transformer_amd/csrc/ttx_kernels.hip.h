@@ -1391,9 +1391,12 @@ struct A3Tile {
 
 // `n_plain` = number of leading keys that every query sees whenever they are real tokens (cached prefix and front
 // token, or all encoder positions): tiles made of such keys skip the per-key flag arithmetic altogether.
+// `lin_limit`, `klin`, `vlin`, `lin_ld`: keys below lin_limit sit at klin/vlin + key * lin_ld (the cache, or the encoder
+// memory): a tile made of such keys takes its addresses from one base instead of sixteen per-key selections.
 template <int MODE, typename KeyPtr, typename KeyOwn, typename KeyFlag, typename QFlag>
-__device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int nk, int n_plain, KeyPtr keyptr, KeyOwn keyown,
-                                           KeyFlag keyflag, QFlag qflag, float* out, int ldo, float scale) {
+__device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int nk, int n_plain, int lin_limit, const float* klin,
+                                           const float* vlin, int lin_ld, KeyPtr keyptr, KeyOwn keyown, KeyFlag keyflag,
+                                           QFlag qflag, float* out, int ldo, float scale) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   // B operand of S^T: query r, dims 8g + 4h .. +3 (rows past nq repeat the last query; they are never stored)
@@ -1416,6 +1419,18 @@ __device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int 
   // costs a branch and a full vmcnt(0) round trip each
   auto load_tile = [&](int key0) {
     A3Tile tl;
+    if (key0 + 32 <= lin_limit) {                   // uniform: all 32 keys exist and are laid out linearly
+      const float* kp = klin + (size_t)(key0 + r) * lin_ld + 4 * h;
+      tl.k0 = *reinterpret_cast<const float4*>(kp);
+      tl.k1 = *reinterpret_cast<const float4*>(kp + 8);
+      tl.k2 = *reinterpret_cast<const float4*>(kp + 16);
+      tl.k3 = *reinterpret_cast<const float4*>(kp + 24);
+      tl.own = keyown(key0 + r);
+      const float* vp = vlin + (size_t)(key0 + 4 * h) * lin_ld + r;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) tl.v[t] = vp[(size_t)((t & 3) + 8 * (t >> 2)) * lin_ld];
+      return tl;
+    }
     const float *kp, *vp;
     const int kown = min(key0 + r, nk - 1);
     keyptr(kown, kp, vp);
@@ -1547,7 +1562,7 @@ __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
     const int n_hi = (rlast == 0) ? -1 : (rlast - 1) / D;
     const int kr0 = 1 + n_lo * D;
     const int n_draft_keys = (n_hi >= n_lo && D > 0) ? (n_hi - n_lo + 1) * D : 0;
-    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, f + 1 + n_draft_keys, f + 1,
+    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, f + 1 + n_draft_keys, f + 1, f, kc, vc, dd,
                      [=](int key, const float*& kp, const float*& vp) {
                        const bool cached = key < f;
                        const int srow = (key == f) ? 0 : kr0 + (key - f - 1);
@@ -1576,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
     const float* vb = a.v + mrow0 * a.ldkv + hd;
     const int ld = a.ldkv;
     const int nkeys = a.src_len ? a.src_len[b] : a.Lk;
-    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, nkeys, ((nkeys + 31) & ~31),
+    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, nkeys, ((nkeys + 31) & ~31), nkeys, kb, vb, ld,
                      [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                      [=](int key) { return (int)kvalid[key]; },
                      [=](int, unsigned real) { return real ? A2_ALL : A2_MASKED; },
