@@ -889,6 +889,7 @@ struct GenJob {
   int launched = 0;
   int phase = 0;          // 0 idle, 1 running, 2 finishing
   int batch = -1;
+  unsigned idle_spins = 0;
 };
 
 static int gen_validate(const ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p, const int64_t* d_out,
@@ -1256,6 +1257,7 @@ struct PoolJob {
   int launched = 0;
   int phase = 0;            // 0 not started, 1 running, 2 finishing, 3 done
   int admits = 0;
+  unsigned idle_spins = 0;
   long long admitted_rows = 0, src_tokens_padded = 0;
 };
 
@@ -1445,7 +1447,19 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
       ttx_session* s = j.s;
       volatile HostInfo* hi = s->host_info;
       if (j.phase == 1) {
-        if (j.launched > 0 && hi->steps_done < j.launched) continue;          // the step in flight has not published yet
+        if (j.launched > 0 && hi->steps_done < j.launched) {                  // the step in flight has not published yet
+          // never spin forever: a stream that has drained without publishing means the step died
+          if ((++j.idle_spins & 0xffff) == 0) {
+            const hipError_t q = hipStreamQuery(j.st);
+            if (q != hipErrorNotReady && hi->steps_done < j.launched) {
+              rc_final = fail(TTX_ERR_HIP, q == hipSuccess ? "verify step finished without publishing its result"
+                                                            : std::string("verify step failed: ") + hipGetErrorString(q));
+              break;
+            }
+          }
+          continue;
+        }
+        j.idle_spins = 0;
         int n_act = (j.launched == 0) ? 0 : hi->n_active;
         const int free_slots = C - n_act;
         if (cursor < R_total && (n_act == 0 || free_slots >= min_admit)) {
@@ -1551,6 +1565,16 @@ static int generate_many_impl(ttx_session** sessions, int n_sessions, int n_batc
           int rc = gen_launch_step(j, hi->width + D1);
           if (rc != TTX_OK) { rc_final = rc; done = n_batches; break; }
           progressed = true;
+          j.idle_spins = 0;
+        } else if (j.launched > 0 && (++j.idle_spins & 0xffff) == 0) {
+          // never spin forever: a stream that has drained without publishing means the step died
+          const hipError_t q = hipStreamQuery(s->own_stream);
+          if (q != hipErrorNotReady && hi->steps_done < j.launched && !hi->stop) {
+            rc_final = fail(TTX_ERR_HIP, q == hipSuccess ? "verify step finished without publishing its result"
+                                                          : std::string("verify step failed: ") + hipGetErrorString(q));
+            done = n_batches;
+            break;
+          }
         }
       } else if (j.phase == 2) {
         if (hipEventQuery(s->ev_done) == hipSuccess) {
