@@ -297,6 +297,7 @@ struct ttx_session {
   // profiling of the GEMM launches (bench.py roofline)
   bool profile = false;
   bool gemm_v1 = false, attn_v1 = false, attn_v3 = true;
+  int attn_split = -1;             // TTX_ATTN_SPLIT: -1 by launch size, 0 never, 1 always (key tiles of a head over 4 waves)
   bool tree_big_policy = false;    // TTX_TREE_BIG_POLICY=1: beam paths under the large-row-count GEMM policy too
   int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
   int fuse_ln_min_rows = 0;        // d-wide GEMM + LayerNorm fused (k_gemm_ln256) from this row capacity on; 0: never (slower)
@@ -380,6 +381,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   if (const char* f2 = getenv("TTX_FFN2_SPLIT")) s->ffn2_split = std::max(1, atoi(f2));
   if (const char* ps = getenv("TTX_PROJ_SPLIT")) s->proj_split = std::max(1, atoi(ps));
   if (const char* a3 = getenv("TTX_ATTN_V3")) s->attn_v3 = atoi(a3) != 0;
+  if (const char* sp = getenv("TTX_ATTN_SPLIT")) s->attn_split = atoi(sp);
   if (const char* tb = getenv("TTX_TREE_BIG_POLICY")) s->tree_big_policy = atoi(tb) != 0;
   if (const char* fl = getenv("TTX_FUSE_LN_MIN_ROWS")) s->fuse_ln_min_rows = std::max(0, atoi(fl));
   if (const char* bt = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(bt));
@@ -533,7 +535,14 @@ static int launch_attn(ttx_session* s, hipStream_t st, const AttnArgs& a, int gr
   if constexpr (step) {
     // the verify step: one wave per (sequence, head, 32 step rows), registers only — no key-count limit
     if (s->attn_v3 && H % 4 == 0 && !s->attn_v1) {
-      hipLaunchKernelGGL((k_attn3<MODE>), dim3(groups, H / 4, cdiv(q_per_group, A3_QT)), dim3(256), 0, st, a);
+      // few sequences (a 32-row batch): the key tiles of one (sequence, head) are shared out over the four waves of
+      // a workgroup; many (row groups, slot pools): one wave per (sequence, head).  Bit-identical either way.
+      const int qtiles = cdiv(q_per_group, A3_QT);
+      const int keys3 = (MODE == ATT_STEP_SELF) ? max_keys + 1 + N * std::max(D, 0) : max_keys;
+      const size_t lds3 = sizeof(float) * (size_t)A3_PART * cdiv(keys3, 32);
+      const bool split = s->attn_split != 0 && (s->attn_split > 0 || (long long)groups * H * qtiles < 2048) && lds3 <= 64 * 1024;
+      if (split) hipLaunchKernelGGL((k_attn3<MODE, true>), dim3(groups, H, qtiles), dim3(256), lds3, st, a);
+      else hipLaunchKernelGGL((k_attn3<MODE, false>), dim3(groups, H / 4, qtiles), dim3(256), 0, st, a);
       HIP_TRY(hipGetLastError());
       return TTX_OK;
     }

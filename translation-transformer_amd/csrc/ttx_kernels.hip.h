@@ -1393,10 +1393,26 @@ struct A3Tile {
 // token, or all encoder positions): tiles made of such keys skip the per-key flag arithmetic altogether.
 // `lin_limit`, `klin`, `vlin`, `lin_ld`: keys below lin_limit sit at klin/vlin + key * lin_ld (the cache, or the encoder
 // memory): a tile made of such keys takes its addresses from one base instead of sixteen per-key selections.
-template <int MODE, typename KeyPtr, typename KeyOwn, typename KeyFlag, typename QFlag>
+//
+// Arithmetic (the same whichever wave computes a tile): every 32-key tile i yields a partial (m_i, l_i, O_i) with its
+// own maximum; the partials are folded IN TILE ORDER into (M, L, O) by  M' = max(M, m_i),  L' = L e^(M-M') + l_i e^(m_i-M'),
+// O' likewise.  SPLIT = false: one wave does all tiles of its (sequence, head) and folds as it goes.  SPLIT = true: the four
+// waves of a workgroup take tiles w, w+4, ... of ONE (sequence, head), park the partials in LDS and then fold them in
+// tile order (wave w finishing dims 8w + 4h .. +3): bit-identical results, four times the parallelism — used when few
+// sequences are decoded (a 32-row batch), chosen by the host from the launch size.
+__device__ __forceinline__ void a3_fold(float& M, float& L, float mi, float li, float& a, float& b) {
+  const float Mn = fmaxf(M, mi);
+  a = (M == -INFINITY) ? 0.f : __expf(M - Mn);
+  b = (mi == -INFINITY) ? 0.f : __expf(mi - Mn);
+  L = __fmaf_rn(L, a, __fmul_rn(li, b));
+  M = Mn;
+}
+constexpr int A3_PART = 16 * 64 + 64;          // floats of one parked tile partial: O_i [16][64], m_i [32], l_i [32]
+
+template <int MODE, bool SPLIT, typename KeyPtr, typename KeyOwn, typename KeyFlag, typename QFlag>
 __device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int nk, int n_plain, int lin_limit, const float* klin,
                                            const float* vlin, int lin_ld, KeyPtr keyptr, KeyOwn keyown, KeyFlag keyflag,
-                                           QFlag qflag, float* out, int ldo, float scale) {
+                                           QFlag qflag, float* out, int ldo, float scale, float* lds) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   // B operand of S^T: query r, dims 8g + 4h .. +3 (rows past nq repeat the last query; they are never stored)
@@ -1449,13 +1465,15 @@ __device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int 
   };
 
   const int ntiles = (nk + 31) >> 5;
-  A3Tile cur = load_tile(0);
-  for (int it = 0; it < ntiles; ++it) {
+  const int wave = SPLIT ? (int)(threadIdx.x >> 6) : 0;
+  constexpr int TSTEP = SPLIT ? 4 : 1;
+  A3Tile cur = load_tile(min(wave, ntiles - 1) * 32);
+  for (int it = wave; it < ntiles; it += TSTEP) {
     const int key0 = it * 32;
     // the next tile's loads go out before this tile's arithmetic (the empty asm keeps them above it); the copy at the
     // bottom of the loop is where they are waited for
 #ifndef TTX_A3_NOPREFETCH
-    A3Tile nxt = load_tile(min(it + 1, ntiles - 1) * 32);
+    A3Tile nxt = load_tile(min(it + TSTEP, ntiles - 1) * 32);
     asm volatile("" ::: "memory");
 #endif
     f32x16 sacc;
@@ -1498,28 +1516,53 @@ __device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int 
         mx = fmaxf(mx, sacc[t]);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m, mx);
-    const float base = (m_new == -INFINITY) ? 0.f : m_new;           // nothing visible yet: every exp below is exp(-inf) = 0
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                               // m_i
+    const float base = (mx == -INFINITY) ? 0.f : mx;                  // nothing visible in this tile: every exp below is 0
     float rs = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       sacc[t] = __expf(sacc[t] - base);
       rs += sacc[t];
     }
-    rs += __shfl_xor(rs, 32);
-    const float alpha = __expf(m - base);                             // m = -inf -> 0
-    l = l * alpha + rs;
-    m = m_new;
+    rs += __shfl_xor(rs, 32);                                          // l_i
+    f32x16 oi;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] *= alpha;
+    for (int i = 0; i < 16; ++i) oi[i] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) o = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[t], sacc[t], o, 0, 0, 0);
+    for (int t = 0; t < 16; ++t) oi = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[t], sacc[t], oi, 0, 0, 0);
+    if constexpr (!SPLIT) {
+      float fa, fb;
+      a3_fold(m, l, mx, rs, fa, fb);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] = __fmaf_rn(o[i], fa, __fmul_rn(oi[i], fb));
+    } else {
+      float* part = lds + (size_t)it * A3_PART;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) part[i * 64 + lane] = oi[i];
+      if (h == 0) { part[16 * 64 + r] = mx; part[16 * 64 + 32 + r] = rs; }
+    }
 #ifndef TTX_A3_NOPREFETCH
     cur = nxt;
 #else
-    if (it + 1 < ntiles) cur = load_tile((it + 1) * 32);
+    if (it + TSTEP < ntiles) cur = load_tile((it + TSTEP) * 32);
 #endif
+  }
+  if constexpr (SPLIT) {
+    __syncthreads();
+    float o4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < ntiles; ++it) {            // the same fold, in tile order; this wave owns values 4w .. 4w+3
+      const float* part = lds + (size_t)it * A3_PART;
+      float fa, fb;
+      a3_fold(m, l, part[16 * 64 + r], part[16 * 64 + 32 + r], fa, fb);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o4[c] = __fmaf_rn(o4[c], fa, __fmul_rn(part[(4 * wave + c) * 64 + lane], fb));
+    }
+    if (r < nq) {
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      f32x4 w = {o4[0] * inv, o4[1] * inv, o4[2] * inv, o4[3] * inv};
+      *reinterpret_cast<f32x4*>(out + (size_t)r * ldo + 4 * h + 8 * wave) = w;
+    }
+    return;
   }
   // o[v] = O[query r][dim (v&3) + 8(v>>2) + 4h]: four float4 per lane
   if (r < nq) {
@@ -1534,12 +1577,13 @@ __device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int 
 }
 
 constexpr int A3_QT = 32;            // step rows per wave
-template <int MODE>
+template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
   static_assert(MODE == ATT_STEP_SELF || MODE == ATT_STEP_CROSS, "k_attn3 serves the verify step");
+  extern __shared__ __attribute__((aligned(16))) float a3_lds[];      // SPLIT: one A3_PART per key tile
   const int slot = blockIdx.x;
   if (slot >= a.st->n_active) return;
-  const int head = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int head = SPLIT ? (int)blockIdx.y : (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
   const int hd = head * ATT_DH;
   const int D = a.D, RPS = step_rps(a.N, a.D);
   const int r0 = blockIdx.z * A3_QT;
@@ -1562,7 +1606,7 @@ __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
     const int n_hi = (rlast == 0) ? -1 : (rlast - 1) / D;
     const int kr0 = 1 + n_lo * D;
     const int n_draft_keys = (n_hi >= n_lo && D > 0) ? (n_hi - n_lo + 1) * D : 0;
-    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, f + 1 + n_draft_keys, f + 1, f, kc, vc, dd,
+    attn3_core<MODE, SPLIT>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, f + 1 + n_draft_keys, f + 1, f, kc, vc, dd,
                      [=](int key, const float*& kp, const float*& vp) {
                        const bool cached = key < f;
                        const int srow = (key == f) ? 0 : kr0 + (key - f - 1);
@@ -1583,7 +1627,7 @@ __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
                        const int qn = (qr - 1) / D;
                        return a2_flag(qn - n_lo, qr - 1 - qn * D);
                      },
-                     a.out + (srow0 + r0) * a.d + hd, a.d, a.scale);
+                     a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, a3_lds);
   } else {
     const size_t mrow0 = (size_t)(a.src_of ? a.src_of[b] : b) * a.Lk;
     const uint8_t* kvalid = a.key_pad + mrow0;
@@ -1591,12 +1635,12 @@ __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
     const float* vb = a.v + mrow0 * a.ldkv + hd;
     const int ld = a.ldkv;
     const int nkeys = a.src_len ? a.src_len[b] : a.Lk;
-    attn3_core<MODE>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, nkeys, ((nkeys + 31) & ~31), nkeys, kb, vb, ld,
+    attn3_core<MODE, SPLIT>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, nkeys, ((nkeys + 31) & ~31), nkeys, kb, vb, ld,
                      [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                      [=](int key) { return (int)kvalid[key]; },
                      [=](int, unsigned real) { return real ? A2_ALL : A2_MASKED; },
                      [](int) { return 0; },
-                     a.out + (srow0 + r0) * a.d + hd, a.d, a.scale);
+                     a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, a3_lds);
   }
 }
 
