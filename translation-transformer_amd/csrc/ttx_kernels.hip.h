@@ -906,7 +906,9 @@ __global__ __launch_bounds__(64) void k_attn(AttnArgs a) {
       const float* kb = a.k + mrow0 * a.ldkv + hd;
       const float* vb = a.v + mrow0 * a.ldkv + hd;
       const int ld = a.ldkv;
-      attn_core(a.q + (srow0 + q0) * a.ldq + hd, a.ldq, nq, a.Lk,
+      // slot pool: only the slot's own source positions hold data (the rest of its row is stale or uninitialised,
+      // and a masked key's V still enters 0 * V)
+      attn_core(a.q + (srow0 + q0) * a.ldq + hd, a.ldq, nq, a.src_len ? a.src_len[b] : a.Lk,
                 [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                 [=](int, int key) { return kv[key] != 0; },
                 a.out + (srow0 + q0) * a.d + hd, a.d, a.scale, lds);
@@ -1228,7 +1230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       const float* kb = a.k + mrow0 * a.ldkv + hd;
       const float* vb = a.v + mrow0 * a.ldkv + hd;
       const int ld = a.ldkv;
-      attn2_core(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, a.Lk,
+      attn2_core(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, a.src_len ? a.src_len[b] : a.Lk,   // see k_attn: slot pool
                  [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
                  [=](int key) { return kv[key] != 0 ? A2_ALL : A2_MASKED; }, q_any,
                  a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, lds, a2_qcap(RPS),
@@ -1719,7 +1721,8 @@ __global__ __launch_bounds__(256) void k_argmax(const float* logits, int V, int*
     const int oi = __shfl_xor(bi, o, 64);
     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
   }
-  if (lane == 0) pred[row] = bi;
+  // a row of NaNs compares false everywhere: never hand an out-of-range token id to the embedding lookup
+  if (lane == 0) pred[row] = (bi < V) ? bi : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
