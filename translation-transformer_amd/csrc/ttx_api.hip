@@ -355,6 +355,13 @@ static int ensure(Buf& b, size_t bytes, hipStream_t st) {
   size_t want = bytes + bytes / 8 + 256;
   if (hipMalloc(&b.p, want) != hipSuccess) return fail(TTX_ERR_NOMEM, "hipMalloc failed for " + std::to_string(want) + " bytes");
   b.cap = want;
+  // TTX_POISON_WORKSPACES=1 (tests): fresh workspaces are filled with 0xFF bytes (NaN as floats, -1 as ints), so that
+  // any dependence on never-written workspace memory shows up deterministically instead of once in a while
+  static const bool poison = getenv("TTX_POISON_WORKSPACES") != nullptr && atoi(getenv("TTX_POISON_WORKSPACES")) != 0;
+  if (poison) {
+    if (hipMemset(b.p, 0xFF, want) != hipSuccess) return fail(TTX_ERR_HIP, "hipMemset (poison) failed");
+    (void)hipDeviceSynchronize();
+  }
   return TTX_OK;
 }
 
