@@ -258,3 +258,20 @@ def test_slot_pool_randomised_partitions(tta, tiny):
             checked += 1
     print(f"{checked} randomised schedules checked, {fell_back} fell back to decoding as given")
     assert checked >= 16 and fell_back == 0
+
+
+def test_out_of_range_token_ids_raise_like_torch_embedding(tta, tiny):
+    src, _, c, V = fixture_tokens()
+    bad = src[:3].clone()
+    bad[1, 2] = V + 5
+    g = tta.TranslationInferenceGreedySpeculative(tiny, 150, 10, 3, PAD, BOS, EOS, c)
+    with pytest.raises(IndexError):
+        g.generate(bad.cuda())
+    with pytest.raises(IndexError):
+        g.generate_many([src[:2].cuda(), bad.cuda()], reorder=True)
+    with pytest.raises(IndexError):
+        tiny.encode_src(bad.cuda())
+    neg = src[:2].clone()
+    neg[0, 1] = -1
+    with pytest.raises(IndexError):
+        tta.TranslationInferenceGreedy(tiny, 150, PAD, BOS, EOS).generate(neg.cuda())

@@ -641,7 +641,7 @@ static int run_encoder(ttx_session* s, hipStream_t st, const int* tok, const uin
   float* ao = s->ao.as<float>();
   float* hb = s->hbuf.as<float>();
   EmbedArgs e{};
-  e.table = m->p(m->src_emb); e.pe = m->p(m->pe); e.X = x; e.d = d; e.tok = tok; e.rows = M; e.L = Ls;
+  e.table = m->p(m->src_emb); e.pe = m->p(m->pe); e.X = x; e.d = d; e.V = c.src_vocab_size; e.tok = tok; e.rows = M; e.L = Ls;
   hipLaunchKernelGGL((k_embed<false>), dim3(cdiv(M, 4)), dim3(256), 0, st, e);
   HIP_TRY(hipGetLastError());
   for (int l = 0; l < c.num_encoder_layers; ++l) {
@@ -700,7 +700,7 @@ static int run_decoder_full(ttx_session* s, hipStream_t st, const int* tok, int 
   float* ckv = s->ckv.as<float>();
   const float scale = 1.0f / sqrtf((float)ATT_DH);
   EmbedArgs e{};
-  e.table = m->p(m->tgt_emb); e.pe = m->p(m->pe); e.X = x; e.d = d; e.tok = tok; e.rows = M; e.L = Lt;
+  e.table = m->p(m->tgt_emb); e.pe = m->p(m->pe); e.X = x; e.d = d; e.V = c.vocab_size; e.tok = tok; e.rows = M; e.L = Lt;
   hipLaunchKernelGGL((k_embed<false>), dim3(cdiv(M, 4)), dim3(256), 0, st, e);
   HIP_TRY(hipGetLastError());
   for (int l = 0; l < c.num_decoder_layers; ++l) {
@@ -834,7 +834,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
   const long long cache_layer = (long long)k.B * cache_seq;
 
   EmbedArgs e{};
-  e.table = m->p(m->tgt_emb); e.pe = m->p(m->pe); e.X = x; e.d = d;
+  e.table = m->p(m->tgt_emb); e.pe = m->p(m->pe); e.X = x; e.d = d; e.V = c.vocab_size;
   e.st = dst; e.act_idx = s->act_idx.as<int>(); e.front = s->front.as<int>(); e.gen = s->gen.as<int>(); e.gen_ld = k.gen_ld;
   e.drafts = s->drafts.as<int>(); e.N = k.N; e.D = k.D;
   hipLaunchKernelGGL((k_embed<true>), dim3(cdiv(Mmax, 4)), dim3(256), 0, st, e);

@@ -1650,6 +1650,8 @@ __global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
 // Embedding + positional row (pos + 1); one wave per token row, float4 per lane when d == 256.
 struct EmbedArgs {
   const float* table; const float* pe; float* X; int d;
+  int V;                           // rows of `table`: ids outside [0, V) are looked up as id 0 (memory safety only —
+                                   // the Python layer rejects such inputs like torch's embedding does)
   // full mode: tokens int32 [rows], position = row % L
   const int* tok; int rows; int L;
   // step mode
@@ -1681,6 +1683,7 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
     tok = a.tok[row];
     pos = row % a.L;
   }
+  if ((unsigned)tok >= (unsigned)a.V) tok = 0;
   const float* e = a.table + (size_t)tok * a.d;
   const float* p = a.pe + (size_t)(pos + 1) * a.d;
   float* x = a.X + (size_t)row * a.d;

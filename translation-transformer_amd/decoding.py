@@ -62,6 +62,7 @@ class TranslationInferenceGreedySpeculative:
     def generate(self, src: torch.Tensor) -> torch.Tensor:
         m = self.model
         src = src.to(m.device, torch.int64).contiguous()
+        m.check_tokens(src)
         B, Ls = src.shape
         out = torch.empty((B, 1, self.max_len), dtype=torch.int64, device=m.device)
         p = N.GenParams(self.max_len, self.draft_len, self.n_drafts, self.pad_token, self.bos_token, self.eos_token,
@@ -108,6 +109,8 @@ class TranslationInferenceGreedySpeculative:
                 if e.code != N.TTX_ERR_ROW_REPLAY:
                     raise            # otherwise: a PAD inside a sequence; decode the batches as given
         srcs = [b.to(m.device, torch.int64).contiguous() for b in batches]
+        for b in srcs:
+            m.check_tokens(b)
         outs = [torch.empty((s.shape[0], 1, self.max_len), dtype=torch.int64, device=m.device) for s in srcs]
         n = len(srcs)
         pool = m.session_pool(max(1, min(in_flight, n)))
@@ -162,6 +165,7 @@ class TranslationInferenceGreedySpeculative:
         for s in srcs:
             allsrc[r0:r0 + s.shape[0], :s.shape[1]] = s
             r0 += s.shape[0]
+        m.check_tokens(allsrc)
         pos = torch.arange(1, Lmax + 1, device=m.device)
         lengths = ((allsrc != self.pad_token) * pos).amax(dim=1)
         order, groups = plan_row_groups(lengths.cpu().numpy(), gsz)
@@ -303,6 +307,7 @@ class TranslationInferenceGreedy:
     def generate(self, src: torch.Tensor) -> torch.Tensor:
         m = self.model
         src = src.to(m.device, torch.int64).contiguous()
+        m.check_tokens(src)
         B, Ls = src.shape
         out = torch.empty((B, 1, self.max_len), dtype=torch.int64, device=m.device)
         p = N.GenParams(self.max_len, 0, 1, self.pad_token, self.bos_token, self.eos_token, self.pad_token, 0)

@@ -111,11 +111,21 @@ class NativeTransformer:
     def _tokens(self, t: torch.Tensor) -> torch.Tensor:
         return t.to(self.device, torch.int64).contiguous()
 
+    def check_tokens(self, t: torch.Tensor, vocab: int | None = None) -> None:
+        """torch.nn.Embedding raises IndexError on ids outside the table (the reference's first op on `src`); so do the
+        generators here, before the ids reach a kernel (which would otherwise look them up as id 0)."""
+        if t.numel() == 0:
+            return
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= (vocab or self.src_vocab_size):
+            raise IndexError("index out of range in self")
+
     # -- B5 ------------------------------------------------------------------------------------
     def encode_src(self, src: torch.Tensor, src_pad_mask: torch.Tensor | None = None) -> torch.Tensor:
         """modules.py:110-116.  The mask argument is accepted for signature parity; the library derives
         it as ``src == pad`` exactly as every reference call site does (speculative_decoding.py:60)."""
         src = self._tokens(src)
+        self.check_tokens(src)
         B, Ls = src.shape
         mem = torch.empty((B, Ls, self.emb_dim), dtype=torch.float32, device=self.device)
         N.check(self._lib.ttx_encode_src(self._session, src.data_ptr(), B, Ls, mem.data_ptr(), self._stream()))
