@@ -698,6 +698,35 @@ __global__ __launch_bounds__(256) void k_finish_ln(FinishArgs a) {
   const int c0 = lane * VPL;
   float x[VPL];
   const size_t off = (size_t)row * a.d + c0;
+  if constexpr (VPL == 4) {
+    if (a.n_slabs <= 2) {
+      // the common shapes (one or two slabs): every operand is requested before the first use — the loop version below
+      // waited for each array in turn (five dependent round trips per row).  Same additions in the same order.
+      const float4 r4 = *reinterpret_cast<const float4*>(a.resid + off);
+      const float4 b4 = *reinterpret_cast<const float4*>(a.bias + c0);
+      const float4 p0 = *reinterpret_cast<const float4*>(a.slabs + off);
+      const float4 p1 = *reinterpret_cast<const float4*>(a.slabs + (size_t)(a.n_slabs - 1) * a.slab_stride + off);   // = p0 if one slab
+      const float4 g1 = *reinterpret_cast<const float4*>(a.g1 + c0);
+      const float4 e1 = *reinterpret_cast<const float4*>(a.b1 + c0);
+      const float* g2p = a.g2 ? a.g2 : a.g1;         // clamped: loaded either way, used only if a.g2
+      const float* e2p = a.g2 ? a.b2 : a.b1;
+      const float4 g2 = *reinterpret_cast<const float4*>(g2p + c0);
+      const float4 e2 = *reinterpret_cast<const float4*>(e2p + c0);
+      const uint8_t valid = a.row_valid ? a.row_valid[row] : (uint8_t)1;
+      x[0] = r4.x + b4.x; x[1] = r4.y + b4.y; x[2] = r4.z + b4.z; x[3] = r4.w + b4.w;
+      x[0] += p0.x; x[1] += p0.y; x[2] += p0.z; x[3] += p0.w;
+      if (a.n_slabs == 2) { x[0] += p1.x; x[1] += p1.y; x[2] += p1.z; x[3] += p1.w; }
+      const float ga[4] = {g1.x, g1.y, g1.z, g1.w}, ea[4] = {e1.x, e1.y, e1.z, e1.w};
+      ln_inplace<4>(x, ga, ea, 0, a.d, a.eps);
+      if (a.g2) {
+        const float gb[4] = {g2.x, g2.y, g2.z, g2.w}, eb[4] = {e2.x, e2.y, e2.z, e2.w};
+        ln_inplace<4>(x, gb, eb, 0, a.d, a.eps);
+      }
+      const bool keep = valid != 0;
+      *reinterpret_cast<float4*>(a.Y + off) = make_float4(keep ? x[0] : 0.f, keep ? x[1] : 0.f, keep ? x[2] : 0.f, keep ? x[3] : 0.f);
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < VPL; ++i) x[i] = a.resid[off + i] + a.bias[c0 + i];
   for (int s = 0; s < a.n_slabs; ++s) {
