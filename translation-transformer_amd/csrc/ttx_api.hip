@@ -1450,7 +1450,7 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
   hipEvent_t ready;
   HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(ready, (hipStream_t)stream));
-  const int n_jobs = std::min(n_sessions, cdiv(R_total, std::max(1, capacity / 2)));
+  const int n_jobs = std::min(n_sessions, cdiv(R_total, std::max(1, std::min(capacity / 2, 32))));   // short lists: several small pools
   const int C = std::min(capacity, std::max(1, cdiv(R_total, n_jobs)));      // never more slots than a fair share of the rows
   std::vector<PoolJob> jobs(n_jobs);
   int rc_final = TTX_OK;

@@ -179,7 +179,7 @@ class TranslationInferenceGreedySpeculative:
         if pool:
             # continuous batching: every session keeps `gsz` slots filled from the sorted work list
             # (ttx_greedy_speculative_generate_pool)
-            n_sess = max(1, min(in_flight, max(1, 2048 // gsz), -(-R // max(1, gsz // 2))))
+            n_sess = max(1, min(in_flight, max(1, 2048 // gsz), -(-R // 32)))     # short lists: several small pools overlap
             sessions = m.session_pool(n_sess)
             sess = (C.c_void_p * len(sessions))(*[q.value for q in sessions])
             width = max(2, int(sorted_len[0]))
