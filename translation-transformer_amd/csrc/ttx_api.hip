@@ -1484,7 +1484,12 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
         int n_act = (j.launched == 0) ? 0 : hi->n_active;
         const int free_slots = C - n_act;
         if (cursor < R_total && (n_act == 0 || free_slots >= min_admit)) {
-          const int take = std::min(free_slots, R_total - cursor);
+          // the last rows of the list are shared out over the pools still running, so that they drain together
+          // instead of one pool swallowing the rest and finishing alone
+          int n_running = 0;
+          for (const PoolJob& o : jobs) n_running += (o.phase == 1);
+          const int remaining = R_total - cursor;
+          const int take = std::min({free_slots, remaining, std::max(1, cdiv(remaining, std::max(1, n_running)))});
           const int Ls_new = std::max(2, (int)h_len[cursor]);                 // longest of the chunk (rows are sorted)
           rc_final = pool_admit(j, d_src + (size_t)cursor * Ls_all, Ls_all, take, Ls_new, cursor, d_out, d_traj, d_fin_step);
           if (rc_final != TTX_OK) break;
