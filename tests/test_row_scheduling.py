@@ -92,3 +92,63 @@ def test_plan_row_groups():
     order, groups = plan_row_groups([5, 9, 2, 9, 7], 2)
     assert list(order) == [1, 3, 4, 0, 2]
     assert [(g.start, g.stop) for g in groups] == [(0, 2), (2, 4), (4, 5)]
+
+
+def _replay_loop(traj, fin_step, max_len, D, N=1):
+    """The reference's while-loop written out iteration by iteration (what replay_batch vectorises)."""
+    B = traj.shape[0]
+    running = np.ones(B, dtype=bool)
+    finished = np.zeros(B, dtype=bool)
+    width, t, calls, acc, rows_it = 1, 0, 0, 0, 0
+    while width < max_len and running.any():
+        t += 1
+        before, after = traj[running, t - 1], traj[running, t]
+        assert (before >= 0).all() and (after >= 0).all()
+        width = int(before.max()) + D + 2
+        calls += 1
+        rows_it += int(running.sum())
+        acc += int((after - before - 1).sum())
+        done = running & (fin_step == t)
+        if done.any():
+            if width > max_len:
+                return calls, True, np.zeros(B, dtype=bool), acc, rows_it
+            finished |= done
+            running &= ~done
+    return calls, False, finished, acc, rows_it
+
+
+def test_replay_vectorised_equals_loop_on_random_traces():
+    """Random per-row traces generated under the per-row rule (a row goes on while front + D + 2 < max_len), random
+    finish steps (including finishes beyond max_len, which make the batch raise)."""
+    rng = np.random.default_rng(2024)
+    n_err = 0
+    for trial in range(400):
+        max_len = int(rng.integers(8, 60))
+        D = int(rng.integers(1, min(12, max_len) + 1))
+        B = int(rng.integers(1, 12))
+        traj = np.full((B, max_len + 1), -1, dtype=np.int64)
+        fin = np.zeros(B, dtype=np.int64)
+        for r in range(B):
+            f, t = 0, 0
+            traj[r, 0] = 0
+            target = int(rng.integers(1, max_len + D))            # position of the row's EOS (may be out of reach)
+            while True:
+                step = int(rng.integers(1, D + 2))                  # accepted + 1 bonus token
+                before = f
+                f = min(f + step, max_len + D)
+                t += 1
+                traj[r, t] = f
+                if f >= target:                                     # EOS produced in this step
+                    fin[r] = t
+                    break
+                if before + D + 2 >= max_len or t >= max_len:       # the row alone would stop here
+                    break
+        rep = replay_batch(traj, fin, max_len, D, 1)
+        calls, err, finished, acc, rows_it = _replay_loop(traj, fin, max_len, D, 1)
+        assert rep.error == err, trial
+        assert rep.model_calls == calls, trial
+        assert rep.rows_iterations == rows_it and rep.accepted_tokens == acc, trial
+        if not err:
+            np.testing.assert_array_equal(rep.finished, finished)
+        n_err += err
+    assert 0 < n_err < 400
