@@ -249,6 +249,7 @@ extern "C" void ttx_model_destroy(ttx_model* m) {
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
+  uint64_t* owner_gen = nullptr;   // the owning session's alloc_generation: bumped whenever this buffer moves
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -285,12 +286,18 @@ struct ttx_session {
   Buf dbg_gemm;
   HostInfo* host_info = nullptr;   // pinned + device-mapped, written by the accept kernels
   hipStream_t own_stream = nullptr; // used by the many-batches driver
-  uint64_t alloc_generation = 0;   // bumped whenever a workspace buffer moves (captured graphs hold raw pointers)
+  // Captured graphs hold raw pointers into the workspaces.  EVERY growth of a buffer of this session (whichever entry
+  // point caused it) bumps alloc_generation through Buf::owner_gen; the graph cache remembers the generation it was
+  // captured under and is dropped as soon as the two differ (graphs_current(), called before any replay or capture).
+  uint64_t alloc_generation = 0;
+  uint64_t graphs_generation = 0;
+  bool dead = false;               // a verify step never published its result (watchdog): the stream may still be stuck
   bool use_graphs = true;
   std::map<GraphKey, hipGraphExec_t> graphs;
   std::set<GraphKey> warmed;
   hipEvent_t ev_done = nullptr;
   void drop_graphs() { for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second); graphs.clear(); warmed.clear(); }
+  void graphs_current() { if (graphs_generation != alloc_generation) { drop_graphs(); graphs_generation = alloc_generation; } }
   DecState* host_state = nullptr;  // pinned copy target
   bool attn_attr_set = false;
   size_t attn_lds_limit = 0;
@@ -319,10 +326,8 @@ struct ttx_session {
                                  &pool_io, &memkv_new, &valid_new, &drafts_new, &tk[0], &tk[1], &tv[0], &tv[1],
                                  &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active, &dbg_gemm,
                                  &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state, &leaf_score, &leaf_tok, &leaf_cnt,
-                                 &beam_summary}) all.push_back(b); }
+                                 &beam_summary}) { b->owner_gen = &alloc_generation; all.push_back(b); } }
 };
-
-static thread_local uint64_t* g_alloc_gen = nullptr;   // alloc_generation of the session being sized
 
 // Growing a workspace must not stall the other sessions' streams: hipFree waits for the whole device, so the old
 // allocation is parked here and released at the start of a later top-level call (or when a session is destroyed),
@@ -345,7 +350,7 @@ static void release_retired() {
 static int ensure(Buf& b, size_t bytes, hipStream_t st) {
   (void)st;
   if (bytes <= b.cap) return TTX_OK;
-  if (g_alloc_gen) ++*g_alloc_gen;
+  if (b.owner_gen) ++*b.owner_gen;
   if (b.p) {
     std::lock_guard<std::mutex> lk(g_retired_mu);
     g_retired.push_back(b.p);
@@ -405,6 +410,10 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
   if (s->host_timing && s->host_launches)
     fprintf(stderr, "[ttx host timing] hipGraphLaunch: %lld launches, %.1f us each\n", s->host_launches,
             s->host_launch_us / (double)s->host_launches);
+  if (s->dead) {        // hipFree / hipDeviceSynchronize would wait for the stuck stream, and a late kernel may still write
+    delete s;           // the mapped host words: leak workspaces, pinned memory, graphs and events of a hung session
+    return;
+  }
   release_retired();
   (void)hipDeviceSynchronize();
   for (Buf* b : s->all)
@@ -894,8 +903,29 @@ static int launch_accept_and_commit(ttx_session* s, hipStream_t st, const GenCtx
 
 // The polling loops give up after this long without a published step (a failed kernel never publishes).
 static bool watchdog_expired(std::chrono::steady_clock::time_point since) {
-  return std::chrono::steady_clock::now() - since > std::chrono::seconds(120);
+  static const int limit_s = [] { const char* e = getenv("TTX_WATCHDOG_SECONDS"); return e && atoi(e) > 0 ? atoi(e) : 120; }();
+  return std::chrono::steady_clock::now() - since > std::chrono::seconds(limit_s);
 }
+
+// A verify step did not publish within the watchdog time.  The stream may be stuck for good, so NOTHING here (or in the
+// callers, on this path) synchronises it: the session is marked unusable, every later call on it fails at once, and
+// destroying it leaks its workspaces instead of waiting for the device.  The process should report the error and exit
+// non-zero (or continue in a fresh child process); it must not re-exec itself after having touched the GPU.
+static int session_hung(ttx_session* s) {
+  s->dead = true;
+  return fail(TTX_ERR_HIP, "verify step did not publish its result within the watchdog time; the session is unusable "
+                           "(its stream was NOT synchronised) - exit the process or continue in a fresh child process");
+}
+
+static int session_alive(const ttx_session* s) {
+  if (s && s->dead) return fail(TTX_ERR_HIP, "this session hung in an earlier call and is unusable");
+  return TTX_OK;
+}
+
+struct EventGuard {              // destroys the event on every exit path
+  hipEvent_t e = nullptr;
+  ~EventGuard() { if (e) (void)hipEventDestroy(e); }
+};
 
 // One generate call in flight on one session: start (encoder, drafts, loop init) -> steps -> finish.
 struct GenJob {
@@ -952,8 +982,6 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   g.k.gen_ld = max_len + D + 2;
   const size_t Mmax = (size_t)B * step_rps(N, D);
 
-  const uint64_t gen_before = s->alloc_generation;
-  g_alloc_gen = &s->alloc_generation;
   TTX_TRY(ensure(s->tok_src, (size_t)B * Ls * 4, st));
   TTX_TRY(ensure(s->src_valid, (size_t)B * Ls, st));
   TTX_TRY(ensure(s->memory, (size_t)B * Ls * d * 4, st));
@@ -989,8 +1017,7 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   TTX_TRY(ensure_acts(s, st, Macts, 1));
   TTX_TRY(ensure(s->qkv, std::max((size_t)Ld * Mmax, (size_t)B * Ls) * 3 * d * 4, st));
   TTX_TRY(ensure(s->slab, sizeof(float) * 16 * Macts * d, st));   // no allocation may happen inside a graph capture
-  g_alloc_gen = nullptr;
-  if (s->alloc_generation != gen_before) s->drop_graphs();        // captured pointers are stale
+  s->graphs_current();                                            // captured pointers may be stale
 
   s->ev_used = 0;
   HIP_TRY(hipEventRecord(s->ev_a, st));
@@ -1062,6 +1089,7 @@ static int gen_launch_step(GenJob& j, int width_bound) {
     return TTX_OK;
   }
   GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, j.greedy ? 1 : (j.g.la.row_rule ? 2 : 0), kcap};
+  s->graphs_current();
   auto it = s->graphs.find(key);
   if (it == s->graphs.end()) {
     if (!s->warmed.count(key)) {
@@ -1220,6 +1248,7 @@ static int gen_finish_collect(GenJob& j) {
 static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p, int64_t* d_out,
                            ttx_gen_stats* stats, void* stream, bool greedy) {
   TTX_TRY(gen_validate(s, d_src, B, Ls, p, d_out, greedy));
+  TTX_TRY(session_alive(s));
   HIP_TRY(hipSetDevice(s->m->device));
   release_retired();
   // The loop runs on the session's own stream (the caller's may be the legacy null stream, which cannot be
@@ -1241,9 +1270,9 @@ static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, 
     TTX_TRY(gen_launch_step(j, hi->width + D1));
     const int want = j.launched;
     unsigned spins = 0;
-    while (hi->steps_done < want && !hi->stop) {
-      if ((++spins & 0xfff) == 0 && hipStreamQuery(st) == hipSuccess && hi->steps_done < want && !hi->stop)
-        return fail(TTX_ERR_HIP, "verify step finished without publishing its result");
+    const auto since = std::chrono::steady_clock::now();
+    while (hi->steps_done < want && !hi->stop) {            // no HIP call while polling: only the clock
+      if ((++spins & 0xffff) == 0 && watchdog_expired(since)) return session_hung(s);
       __builtin_ia32_pause();
     }
   }
@@ -1300,8 +1329,6 @@ static int pool_start(PoolJob& j, ttx_session* s, hipStream_t st, int C, int Ls_
   g.k.gen_ld = max_len + D + 2;
   const size_t Mmax = (size_t)C * step_rps(N, D);
   const size_t kv_row = (size_t)Ld * 2 * d;
-  const uint64_t gen_before = s->alloc_generation;
-  g_alloc_gen = &s->alloc_generation;
   TTX_TRY(ensure(s->tok_src, (size_t)C * Ls_cap * 4, st));
   TTX_TRY(ensure(s->valid_new, (size_t)C * Ls_cap, st));
   TTX_TRY(ensure(s->src_valid, (size_t)C * Ls_cap, st));
@@ -1323,8 +1350,7 @@ static int pool_start(PoolJob& j, ttx_session* s, hipStream_t st, int C, int Ls_
   TTX_TRY(ensure_acts(s, st, Macts, 1));
   TTX_TRY(ensure(s->qkv, std::max((size_t)Ld * Mmax, (size_t)C * Ls_cap) * 3 * d * 4, st));
   TTX_TRY(ensure(s->slab, sizeof(float) * 16 * Macts * d, st));
-  g_alloc_gen = nullptr;
-  if (s->alloc_generation != gen_before) s->drop_graphs();
+  s->graphs_current();
 
   s->ev_used = 0;
   HIP_TRY(hipEventRecord(s->ev_a, st));
@@ -1398,6 +1424,7 @@ static int pool_launch_step(PoolJob& j) {
   const int kcap = k.max_len;
   const bool use_graph = s->use_graphs && !s->profile;
   GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, 3, kcap};
+  s->graphs_current();
   auto it = s->graphs.find(key);
   if (!use_graph || (it == s->graphs.end() && !s->warmed.count(key))) {
     s->warmed.insert(key);          // first use of a shape runs eagerly once (function attributes are set outside capture)
@@ -1447,9 +1474,12 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
   TTX_TRY(gen_validate(sessions[0], d_src, capacity, Ls_cap, p, d_out, false));
   HIP_TRY(hipSetDevice(sessions[0]->m->device));
   release_retired();
-  hipEvent_t ready;
-  HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  for (int i = 0; i < n_sessions; ++i) TTX_TRY(session_alive(sessions[i]));
+  EventGuard ready_guard;
+  HIP_TRY(hipEventCreateWithFlags(&ready_guard.e, hipEventDisableTiming));
+  hipEvent_t ready = ready_guard.e;
   HIP_TRY(hipEventRecord(ready, (hipStream_t)stream));
+  bool hung = false;
   const int n_jobs = std::min(n_sessions, cdiv(R_total, std::max(1, std::min(capacity / 2, 32))));   // short lists: several small pools
   const int C = std::min(capacity, std::max(1, cdiv(R_total, n_jobs)));      // never more slots than a fair share of the rows
   std::vector<PoolJob> jobs(n_jobs);
@@ -1474,7 +1504,8 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
         if (j.launched > 0 && hi->steps_done < j.launched) {                  // the step in flight has not published yet
           // never spin forever (no HIP call in the polling loop: only the clock)
           if ((++j.idle_spins & 0xffff) == 0 && watchdog_expired(j.last_progress)) {
-            rc_final = fail(TTX_ERR_HIP, "verify step did not publish its result within the watchdog time");
+            rc_final = session_hung(s);
+            hung = true;
             break;
           }
           continue;
@@ -1497,9 +1528,12 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
           n_act += take;
         }
         if (n_act == 0) {
-          HIP_TRY(hipEventRecord(s->ev_c, j.st));
-          HIP_TRY(hipMemcpyAsync(s->host_state, s->state.as<DecState>(), sizeof(DecState), hipMemcpyDeviceToHost, j.st));
-          HIP_TRY(hipEventRecord(s->ev_done, j.st));
+          if (hipEventRecord(s->ev_c, j.st) != hipSuccess ||
+              hipMemcpyAsync(s->host_state, s->state.as<DecState>(), sizeof(DecState), hipMemcpyDeviceToHost, j.st) != hipSuccess ||
+              hipEventRecord(s->ev_done, j.st) != hipSuccess) {
+            rc_final = fail(TTX_ERR_HIP, "slot pool: enqueueing the final state read-back failed");
+            break;
+          }
           j.phase = 2;
         } else {
           if (j.launched > (long long)(p->max_len + 2) * (R_total + 1)) { rc_final = fail(TTX_ERR_HIP, "decode loop failed to terminate"); break; }
@@ -1533,8 +1567,14 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
     }
     if (!progressed) __builtin_ia32_pause();
   }
-  for (int i = 0; i < n_jobs; ++i) (void)hipStreamSynchronize(jobs[i].s->own_stream);
-  (void)hipEventDestroy(ready);
+  if (hung) {
+    // a stream that never published may never drain: do not wait on any of them, and retire every session of this call
+    // (their workspaces may still be written by whatever is stuck)
+    for (int i = 0; i < n_jobs; ++i) jobs[i].s->dead = true;
+  } else {
+    for (int i = 0; i < n_jobs; ++i)
+      if (jobs[i].s && jobs[i].s->own_stream) (void)hipStreamSynchronize(jobs[i].s->own_stream);
+  }
   if (stats) stats->status = rc_final;
   return rc_final;
 }
@@ -1552,9 +1592,12 @@ static int generate_many_impl(ttx_session** sessions, int n_sessions, int n_batc
   release_retired();
   hipStream_t caller = (hipStream_t)stream;
   // inputs were produced on the caller's stream: every session stream waits for it once
-  hipEvent_t ready;
-  HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  for (int i = 0; i < n_sessions; ++i) TTX_TRY(session_alive(sessions[i]));
+  EventGuard ready_guard;
+  HIP_TRY(hipEventCreateWithFlags(&ready_guard.e, hipEventDisableTiming));
+  hipEvent_t ready = ready_guard.e;
   HIP_TRY(hipEventRecord(ready, caller));
+  bool hung = false;
   std::vector<GenJob> jobs(n_sessions);
   for (int i = 0; i < n_sessions; ++i) {
     if (!sessions[i]->own_stream) HIP_TRY(hipStreamCreateWithFlags(&sessions[i]->own_stream, hipStreamNonBlocking));
@@ -1594,7 +1637,8 @@ static int generate_many_impl(ttx_session** sessions, int n_sessions, int n_batc
           j.idle_spins = 0;
           j.last_progress = std::chrono::steady_clock::now();
         } else if (j.launched > 0 && (++j.idle_spins & 0xffff) == 0 && watchdog_expired(j.last_progress)) {
-          rc_final = fail(TTX_ERR_HIP, "verify step did not publish its result within the watchdog time");   // no HIP call while polling
+          rc_final = session_hung(s);                                                       // no HIP call while polling
+          hung = true;
           done = n_batches;
           break;
         }
@@ -1609,9 +1653,11 @@ static int generate_many_impl(ttx_session** sessions, int n_sessions, int n_batc
     }
     if (!progressed) __builtin_ia32_pause();
   }
-  for (int i = 0; i < n_sessions; ++i) (void)hipStreamSynchronize(sessions[i]->own_stream);
-  // later work on the caller's stream must see the outputs
-  (void)hipEventDestroy(ready);
+  if (hung) {
+    for (int i = 0; i < n_sessions; ++i) sessions[i]->dead = true;      // never wait for a stream that may be stuck
+  } else {
+    for (int i = 0; i < n_sessions; ++i) (void)hipStreamSynchronize(sessions[i]->own_stream);
+  }
   return rc_final;
 }
 
@@ -1651,8 +1697,6 @@ extern "C" int ttx_tree_begin(ttx_session* s, const int64_t* d_src, int B, int L
   t.B = B; t.Ls = Ls; t.max_cand = max_cand; t.max_len = max_len; t.N = n_drafts; t.D = draft_len;
   t.Lc = max_len + draft_len + 2; t.gen_ld = max_len + draft_len + 2; t.cur = 0; t.prev_N = 1; t.prev_D = 0; t.steps = 0;
   const size_t Mmax = (size_t)max_cand * step_rps(n_drafts, draft_len);
-  g_alloc_gen = &s->alloc_generation;
-  const uint64_t gen_before = s->alloc_generation;
   int rc = TTX_OK;
   auto need = [&](Buf& b, size_t bytes) { if (rc == TTX_OK) rc = ensure(b, bytes, st); };
   need(s->tok_src, (size_t)B * Ls * 4); need(s->src_valid, (size_t)B * Ls); need(s->memory, (size_t)B * Ls * d * 4);
@@ -1668,8 +1712,7 @@ extern "C" int ttx_tree_begin(ttx_session* s, const int64_t* d_src, int B, int L
   if (rc == TTX_OK) rc = ensure_acts(s, st, Macts, 1);
   need(s->qkv, std::max((size_t)Ld * Mmax, (size_t)B * Ls) * 3 * d * 4);
   need(s->slab, sizeof(float) * 16 * Macts * d);
-  g_alloc_gen = nullptr;
-  if (s->alloc_generation != gen_before) s->drop_graphs();
+  s->graphs_current();
   TTX_TRY(rc);
   TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
   TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));

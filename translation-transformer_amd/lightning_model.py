@@ -114,6 +114,11 @@ class VanillaEncoderDecoderTransformerLightning(LightningModule):
         if device is None:
             p = next(self.model.parameters())
             device = p.device if p.is_cuda else torch.device("cuda:0")
+        if self.src_pad_token_i != self.tgt_pad_token_i:
+            # the reference keeps the two apart (modules.py:44-47); ttx_config carries one pad id, which masks source keys
+            # AND target keys, so a source tokenizer with another pad index would be masked wrongly: refuse it loudly
+            raise ValueError(f"source pad id {self.src_pad_token_i} != target pad id {self.tgt_pad_token_i}: the HIP path "
+                             "supports one shared pad index (the reference's tokenizers fix PAD=0, tokenizer_base.py:27)")
         self.native = NativeTransformer(self.model.state_dict(), self.hparams.num_heads, self.tgt_pad_token_i, device=device)
         self.generator = self._create_generator()
         print(self.generator)
