@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TTX_ABI_VERSION 2
+#define TTX_ABI_VERSION 3
 
 typedef enum ttx_status {
   TTX_OK = 0,
@@ -188,6 +188,45 @@ int ttx_beam_expand(ttx_session* s, const float* d_cl, const int64_t* d_chosen, 
                     const uint8_t* d_finished, int B, int beam, int dl, int V, int K, int pad, int bos, int eos,
                     int64_t* d_new_cand, float* d_new_logp, int32_t* d_parent, int32_t* d_parent_draft, int32_t* d_mark,
                     int32_t* h_summary, void* stream);
+
+/* TranslationInferenceBeamSearchSpeculative.generate (src/decoding/speculative_decoding.py:241-869) — the whole loop on the
+ * device: generate_trying_all_the_drafts (:428-598) or generate_with_smart_drafts (:600-845), `sample` (:294-400),
+ * calculate_n_accepted_in_drafts (:847-869), mask_with_num_logits_according_nucleus (:871-904) and topk_in_each_group
+ * (:177-238), on a per-candidate KV cache (encoder and cross K/V once per source).  Ties between drafts with the same
+ * accepted length are resolved as torch's CPU topk(1) resolves them (csrc/ttx_select.h), so the candidates are those of the
+ * reference run on the CPU.  draft_len is clamped to [5, 200] as the reference's constructor does (:278-284).
+ *   d_src int64 [B, Ls];  d_out int64 [B, n_best, max_len] (row stride max_len): the reference's result tensor
+ *   [B, n_best, W] occupies the first W = stats->out_width columns of every row (W <= max_len), hypotheses best first.
+ * Errors: TTX_ERR_REFERENCE where the reference asserts/raises (fewer candidate leaves than n_best for a source, :195;
+ * no drafts, drafting.py:39-43; max_len < 3); TTX_ERR_INVALID with "max_steps" in the text when the guard below trips. */
+typedef struct ttx_beam_params {
+  int32_t max_len;
+  int32_t n_best;            /* <= 32                                                                  */
+  int32_t draft_len;
+  int32_t n_drafts;          /* <= 64: drafts per candidate (all drafts) / most drafts tried per candidate (smart) */
+  int32_t smart_drafts_mode;
+  int32_t pad_token, bos_token, eos_token, replace_token;
+  int32_t max_steps;         /* 0: none (reference behaviour: its loop does not end when a candidate keeps emitting PAD
+                                before any EOS); > 0: fail once more than this many iterations would be needed */
+} ttx_beam_params;
+
+typedef struct ttx_beam_stats {
+  int64_t model_calls;             /* iterations == decoder invocations (generator.model_calls_num)         */
+  int64_t input_lines;             /* (candidate, draft) rows built over all iterations (model_input_lines_num) */
+  int64_t running_rows;            /* of those, rows of unfinished candidates (the reference's b_sz)        */
+  int64_t accepted_tokens;         /* generator.accepted_tokens_num                                         */
+  int64_t produced_non_pad_tokens; /* generator.produced_non_pad_tokens                                     */
+  int32_t out_width;               /* W: columns of the result tensor                                       */
+  int32_t status;                  /* this batch's own status (the *_many call returns the first failure)   */
+} ttx_beam_stats;
+
+int ttx_beam_speculative_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_beam_params* p,
+                                  int64_t* d_out, ttx_beam_stats* stats, void* stream);
+/* Several batches in flight (batch i on sessions[i % n_sessions], each on its own stream; one host thread drives all of
+ * them): per-batch outputs and stats are those of n_batches calls of ttx_beam_speculative_generate. */
+int ttx_beam_speculative_generate_many(ttx_session** sessions, int n_sessions, int n_batches, const int64_t* const* d_src,
+                                       const int* B, const int* Ls, const ttx_beam_params* p, int64_t* const* d_out,
+                                       ttx_beam_stats* stats, void* stream);
 
 /* Several batches in flight on one GPU (the scheduling SURVEY.md §8(f) #1 names; the reference's predict loop
  * is strictly one batch at a time, src/model/lightning_model.py:209-212).  Batch i is decoded on

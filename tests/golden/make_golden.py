@@ -10,7 +10,7 @@ contains reference source text: the fixtures are token ids, weights trained by t
 output arrays.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
-Sections: tokens tiny model fullsize drafts greedy beam spec_greedy spec_beam helpers   (default: all)
+Sections: tokens tiny model fullsize drafts greedy beam spec_greedy spec_beam helpers tiny66 spec_beam66  (default: all)
 """
 import json
 import os
@@ -378,6 +378,109 @@ def section_spec_beam():
     print("spec beam ok")
 
 
+# --------------------------------------------------------------------------------------
+# Config C4's shape in miniature: a 6+6-layer model (configs/cfg_standard_single_step_retrosyn.yaml:96-103) and the
+# reference's beam-speculative generator at bs=8, n_best=10, n_drafts=2, draft_len=10, max_len=200
+# (scripts/single_step_retrosynthesis.sh:166-174), both draft modes.
+TINY66 = dict(num_encoder_layers=6, num_decoder_layers=6, embedding_dim=64, num_heads=2, feedforward_dim=128)
+
+
+def section_tiny66():
+    src, tgt, c_tok, V = fixture_tokens()
+    torch.manual_seed(654321)
+    model = build_ref_model(V, TINY66)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss(reduction="mean")
+    model.train()
+    for step in range(6000):
+        logits = model(src, tgt[:, :-1])
+        loss = crit(logits.reshape(-1, V), tgt[:, 1:].reshape(-1))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if step % 100 == 0:
+            print("tiny66 step", step, "loss", float(loss), flush=True)
+        if float(loss) < 2e-3:
+            break
+    model.eval()
+    with torch.inference_mode():
+        g = TranslationInferenceGreedy(model, 150, PAD, BOS, EOS).generate(src)
+    ok = 0
+    for i in range(src.size(0)):
+        L = int((tgt[i] != PAD).sum())
+        ok += int(torch.equal(g[i, 0, :L], tgt[i, :L]))
+    print("tiny66: final loss", float(loss), "steps", step, "greedy exact", ok, "/ 10")
+    assert ok == 10
+    state_to_npz(model, HERE / "tiny66_weights.npz")
+    (HERE / "tiny66_config.json").write_text(json.dumps(dict(TINY66, vocab_size=V, share_embeddings=True)))
+
+
+def section_spec_beam66():
+    src, _, c_tok, V = fixture_tokens()
+    m = build_ref_model(V, TINY66)
+    load_state(m, HERE / "tiny66_weights.npz")
+    m.eval()
+    real_decode = m.decode_tgt
+    calls = [0]
+
+    class NotTerminating(Exception):
+        pass
+
+    def capped(*a, **k):
+        calls[0] += 1
+        if calls[0] >= 400:
+            raise NotTerminating()
+        return real_decode(*a, **k)
+
+    m.decode_tgt = capped
+
+    def make(smart, nbest, N, D):
+        return TranslationInferenceBeamSearchSpeculative(
+            m, max_len=200, n_best=nbest, draft_len=D, n_drafts=N, vocab_size=V, smart_drafts_mode=smart,
+            pad_token=PAD, bos_token=BOS, eos_token=EOS, C_token=c_tok)
+
+    out = {}
+    with torch.inference_mode():
+        # rows on which the reference loop terminates in both modes at n_best = 10 (see section_spec_beam's docstring)
+        good = []
+        for r in range(src.size(0)):
+            ok = True
+            for smart in (False, True):
+                calls[0] = 0
+                sel = src[r:r + 1]
+                try:
+                    make(smart, 10, 2, 10).generate(sel[:, :int((sel != PAD).sum())])
+                except NotTerminating:
+                    ok = False
+            print("row", r, "terminates" if ok else "does NOT terminate", flush=True)
+            if ok:
+                good.append(r)
+        cases = [(good[:8], 8, 10, 2, 10), (good[:8], 4, 10, 2, 11), (good[:6], 3, 5, 7, 10)]
+        for smart in (False, True):
+            for ci, (rows, bsz, nbest, N, D) in enumerate(cases):
+                g = make(smart, nbest, N, D)
+                key = f"smart{int(smart)}_case{ci}"
+                out[f"{key}_rows"] = np.array(rows, dtype=np.int64)
+                out[f"{key}_params"] = np.array([bsz, nbest, N, D], dtype=np.int64)
+                nb = 0
+                for bi, i in enumerate(range(0, len(rows), bsz)):
+                    calls[0] = 0
+                    sel = src[rows[i:i + bsz]]
+                    width = int((sel != PAD).sum(1).max())
+                    out[f"{key}_batch{bi}"] = trim_np(g.generate(sel[:, :width]))
+                    nb += 1
+                out[f"{key}_nbatches"] = np.int64(nb)
+                out[f"{key}_calls"] = np.int64(g.model_calls_num)
+                out[f"{key}_accepted"] = np.int64(g.accepted_tokens_num)
+                out[f"{key}_produced"] = np.int64(g.produced_non_pad_tokens)
+                out[f"{key}_lines"] = np.int64(g.model_input_lines_num)
+                print(key, rows, (bsz, nbest, N, D), "calls", g.model_calls_num, "acc", g.accepted_tokens_num,
+                      g.produced_non_pad_tokens, flush=True)
+    m.decode_tgt = real_decode
+    np.savez_compressed(HERE / "gen_spec_beam66.npz", **out)
+    print("spec beam 6+6 ok")
+
+
 def section_helpers():
     """G4: nucleus masking and per-group top-k on fixed tensors."""
     rng = np.random.default_rng(11)
@@ -438,7 +541,8 @@ def section_tokenizer():
 
 SECTIONS = dict(tokenizer=section_tokenizer, tokens=section_tokens, tiny=section_tiny, model=section_model, fullsize=section_fullsize,
                 drafts=section_drafts, greedy=section_greedy, beam=section_beam,
-                spec_greedy=section_spec_greedy, spec_beam=section_spec_beam, helpers=section_helpers)
+                spec_greedy=section_spec_greedy, spec_beam=section_spec_beam, helpers=section_helpers,
+                tiny66=section_tiny66, spec_beam66=section_spec_beam66)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -1,0 +1,197 @@
+"""The native beam-speculative loop (ttx_beam_speculative_generate) against the reference's golden outputs — every
+hypothesis of every source and the three counters, both draft modes, 2+2 and 6+6 layers — and, at the real layer sizes of
+config C4 (d=256, 8 heads, FFN 2048, 6+6 layers; bs=8, n_best=10, n_drafts=2, draft_len=10, max_len=200:
+configs/cfg_standard_single_step_retrosyn.yaml:96-103, scripts/single_step_retrosynthesis.sh:166-174) and C3 (4+4; bs=4,
+n_best=5, n_drafts=7, draft_len=10), against oracle.spec_beam on weights trained in the test."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from util_models import GOLDEN, load_npz, tiny_state, fixture_tokens, upto_eos, PAD, BOS, EOS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tta():
+    import translation_transformer_amd as t
+    assert t.lib().ttx_device_count() >= 1
+    return t
+
+
+def _golden_cases(tta, native, gold, smart, max_len, V, c, lines_key=False):
+    ci, total = 0, 0
+    while f"smart{int(smart)}_case{ci}_rows" in gold:
+        key = f"smart{int(smart)}_case{ci}"
+        rows = gold[key + "_rows"].tolist()
+        bsz, nbest, N, D = gold[key + "_params"].tolist()
+        src, _, _, _ = fixture_tokens()
+        g = tta.TranslationInferenceBeamSearchSpeculative(native, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=400)
+        for bi, i in enumerate(range(0, len(rows), bsz)):
+            sel = src[rows[i:i + bsz]]
+            width = int((sel != PAD).sum(1).max())
+            out = g.generate(sel[:, :width].cuda()).cpu().numpy()
+            ref = gold[f"{key}_batch{bi}"]
+            assert out.shape[:2] == ref.shape[:2]
+            for b in range(out.shape[0]):
+                for k in range(out.shape[1]):
+                    assert upto_eos(out[b, k]) == upto_eos(ref[b, k]), (key, bi, b, k, out[b, k].tolist(), ref[b, k].tolist())
+                    total += 1
+        assert g.model_calls_num == int(gold[key + "_calls"]), key
+        assert g.accepted_tokens_num == int(gold[key + "_accepted"]), key
+        assert g.produced_non_pad_tokens == int(gold[key + "_produced"]), key
+        if lines_key:
+            assert g.model_input_lines_num == int(gold[key + "_lines"]), key
+        ci += 1
+    return ci, total
+
+
+@pytest.mark.parametrize("smart", [False, True])
+def test_every_hypothesis_and_counter_matches_reference(tta, smart):
+    """2+2 tiny model, the reference's outputs of tests/golden/gen_spec_beam.npz: 181 hypotheses per mode, all token-identical
+    (ties between equally long drafts are broken as torch's CPU topk breaks them: csrc/ttx_select.h)."""
+    st, cfg = tiny_state()
+    native = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    _, _, c, V = fixture_tokens()
+    n_cases, total = _golden_cases(tta, native, load_npz("gen_spec_beam.npz"), smart, 150, V, c)
+    assert n_cases >= 7 and total == 181
+
+
+@pytest.mark.parametrize("smart", [False, True])
+def test_six_plus_six_layers_c4_shape_matches_reference(tta, smart):
+    """6+6 layers (config C4's depth) at C4's generator settings (bs 8, n_best 10, n_drafts 2, draft_len 10, max_len 200)
+    and two neighbours, against the reference's own outputs (tests/golden/gen_spec_beam66.npz)."""
+    st = load_npz("tiny66_weights.npz")
+    cfg = json.loads((GOLDEN / "tiny66_config.json").read_text())
+    assert cfg["num_encoder_layers"] == 6 and cfg["num_decoder_layers"] == 6
+    native = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    _, _, c, V = fixture_tokens()
+    n_cases, total = _golden_cases(tta, native, load_npz("gen_spec_beam66.npz"), smart, 200, V, c, lines_key=True)
+    assert n_cases == 3 and total > 100
+
+
+def test_batches_in_flight_equal_one_at_a_time(tta):
+    st, cfg = tiny_state()
+    native = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    src, _, c, V = fixture_tokens()
+    groups = [[0, 2, 3, 4], [5, 6], [8, 9, 0], [2], [3, 4, 5, 6, 8], [9, 2]]
+    batches = []
+    for rows in groups:
+        sel = src[rows]
+        batches.append(sel[:, :int((sel != PAD).sum(1).max())].cuda())
+    for smart in (False, True):
+        one = tta.TranslationInferenceBeamSearchSpeculative(native, 150, 5, 10, 3, V, smart, PAD, BOS, EOS, c, max_steps=400)
+        ref = [one.generate(b) for b in batches]
+        many = tta.TranslationInferenceBeamSearchSpeculative(native, 150, 5, 10, 3, V, smart, PAD, BOS, EOS, c, max_steps=400)
+        out = many.generate_many(batches, in_flight=3)
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+        for name in ("model_calls_num", "accepted_tokens_num", "produced_non_pad_tokens", "model_input_lines_num", "b_sz", "n_drafts"):
+            assert getattr(many, name) == getattr(one, name), name
+
+
+def _train_full(n_layers: int, seed: int):
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from tools.train_synth import TrainModel
+    src, tgt, _, V = fixture_tokens()
+    torch.manual_seed(seed)
+    model = TrainModel(vocab=V, n_enc=n_layers, n_dec=n_layers).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4 if n_layers == 4 else 2e-4)
+    crit = torch.nn.CrossEntropyLoss()
+    s, t = src.cuda(), tgt.cuda()
+    model.train()
+    for step in range(900):
+        loss = crit(model(s, t[:, :-1]).reshape(-1, V), t[:, 1:].reshape(-1))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if loss.item() < 5e-3:
+            break
+    print(f"full-size {n_layers}+{n_layers} fixture model: steps", step, "loss", loss.item())
+    assert loss.item() < 0.05
+    return {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+
+
+def _hyp_logprob(oracle, src_row, hyp):
+    """Cumulative log-probability of a hypothesis (tokens up to its first EOS) under the oracle model."""
+    toks = upto_eos(hyp)
+    while toks and toks[-1] == PAD:
+        toks.pop()
+    t = torch.tensor([toks], dtype=torch.int64)
+    s = src_row[None]
+    mask = s == PAD
+    logits = oracle.decode_tgt(t[:, :-1], oracle.encode_src(s, mask), mask)[0]
+    lp = logits.log_softmax(-1)
+    return float(lp[torch.arange(len(toks) - 1), t[0, 1:]].sum())
+
+
+def _compare_with_oracle(tta, native, oracle, sel, params, label):
+    """HIP vs oracle.spec_beam on one batch.  Top-1 of every source must be identical.  A lower rank may only differ where
+    the oracle itself scores the two hypotheses within 2e-3 of each other (the HIP and CPU forwards agree to ~1e-5 per logit,
+    so two cumulative fp32 scores closer than that can rank either way): every difference is printed with both scores."""
+    from oracle.spec_beam import BeamSearchSpeculativeOracle
+    nbest, D, N, max_len = params
+    _, _, c, V = fixture_tokens()
+    n_diff = n_total = 0
+    for smart in (False, True):
+        ref = BeamSearchSpeculativeOracle(oracle, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=400)
+        exp = ref.generate(sel).numpy()
+        g = tta.TranslationInferenceBeamSearchSpeculative(native, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=400)
+        out = g.generate(sel.cuda()).cpu().numpy()
+        assert out.shape[:2] == exp.shape[:2]
+        exact = True
+        for b in range(out.shape[0]):
+            assert upto_eos(out[b, 0]) == upto_eos(exp[b, 0]), (label, smart, b)
+            for k in range(out.shape[1]):
+                n_total += 1
+                if upto_eos(out[b, k]) != upto_eos(exp[b, k]):
+                    exact = False
+                    n_diff += 1
+                    sa, sb = _hyp_logprob(oracle, sel[b], out[b, k]), _hyp_logprob(oracle, sel[b], exp[b, k])
+                    print(f"{label} smart={smart} source {b} rank {k}: HIP {upto_eos(out[b, k])} ({sa:.6f}) vs oracle "
+                          f"{upto_eos(exp[b, k])} ({sb:.6f}), |delta| = {abs(sa - sb):.2e}")
+                    assert abs(sa - sb) < 2e-3, (label, smart, b, k)
+        if exact:
+            assert g.model_calls_num == ref.model_calls_num
+            assert g.accepted_tokens_num == ref.accepted_tokens_num
+            assert g.produced_non_pad_tokens == ref.produced_non_pad_tokens
+            assert g.model_input_lines_num == ref.model_input_lines_num
+    print(f"{label}: {n_total - n_diff}/{n_total} hypotheses token-identical to the oracle")
+    return n_diff, n_total
+
+
+def test_config_c4_full_size_matches_oracle(tta):
+    """BASELINE config C4 at its real sizes: 6+6 layers of d=256 / 8 heads / FFN 2048, beam-speculative n_best 10, bs 8,
+    n_drafts 2, draft_len 10, max_len 200, both draft modes."""
+    from oracle.model import OracleTransformer, config_from_state
+    st = _train_full(6, 4321)
+    native = tta.NativeTransformer(st, 8, 0, device=0)
+    assert native.num_enc_layers == 6 and native.num_dec_layers == 6
+    oracle = OracleTransformer(config_from_state(st, 8), st)
+    src, _, _, _ = fixture_tokens()
+    rows = [0, 2, 3, 4, 5, 6, 8, 9]
+    sel = src[rows]
+    sel = sel[:, :int((sel != PAD).sum(1).max())]
+    n_diff, n_total = _compare_with_oracle(tta, native, oracle, sel, (10, 10, 2, 200), "C4")
+    assert n_total == 2 * 8 * 10 and n_diff <= 0.05 * n_total
+
+
+def test_config_c3_full_size_matches_oracle(tta):
+    """BASELINE config C3: 4+4 layers, beam-speculative n_best 5, bs 4, n_drafts 7, draft_len 10, max_len 200."""
+    from oracle.model import OracleTransformer, config_from_state
+    st = _train_full(4, 1234)
+    native = tta.NativeTransformer(st, 8, 0, device=0)
+    oracle = OracleTransformer(config_from_state(st, 8), st)
+    src, _, _, _ = fixture_tokens()
+    n_diff = n_total = 0
+    for rows in ([0, 2, 4, 6], [3, 5, 8, 9]):
+        sel = src[rows]
+        sel = sel[:, :int((sel != PAD).sum(1).max())]
+        d, t = _compare_with_oracle(tta, native, oracle, sel, (5, 10, 7, 200), f"C3 rows {rows}")
+        n_diff += d
+        n_total += t
+    assert n_diff <= 0.05 * n_total

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = PKG_DIR / "libttx_hip.so"
-SOURCES = [CSRC / "ttx_api.hip", CSRC / "ttx_kernels.hip.h", CSRC / "ttx_tokenizer.h", INCLUDE / "ttx.h"]
+SOURCES = [CSRC / "ttx_api.hip", CSRC / "ttx_kernels.hip.h", CSRC / "ttx_select.h", CSRC / "ttx_tokenizer.h", INCLUDE / "ttx.h"]
 
 TTX_OK, TTX_ERR_INVALID, TTX_ERR_HIP, TTX_ERR_NO_DEVICE, TTX_ERR_REFERENCE, TTX_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 TTX_ERR_ROW_REPLAY = -6
@@ -45,6 +45,18 @@ class GenParams(C.Structure):
     _fields_ = [("max_len", C.c_int32), ("draft_len", C.c_int32), ("n_drafts", C.c_int32), ("pad_token", C.c_int32),
                 ("bos_token", C.c_int32), ("eos_token", C.c_int32), ("replace_token", C.c_int32),
                 ("want_logits", C.c_int32)]
+
+
+class BeamParams(C.Structure):
+    _fields_ = [("max_len", C.c_int32), ("n_best", C.c_int32), ("draft_len", C.c_int32), ("n_drafts", C.c_int32),
+                ("smart_drafts_mode", C.c_int32), ("pad_token", C.c_int32), ("bos_token", C.c_int32),
+                ("eos_token", C.c_int32), ("replace_token", C.c_int32), ("max_steps", C.c_int32)]
+
+
+class BeamStats(C.Structure):
+    _fields_ = [("model_calls", C.c_int64), ("input_lines", C.c_int64), ("running_rows", C.c_int64),
+                ("accepted_tokens", C.c_int64), ("produced_non_pad_tokens", C.c_int64), ("out_width", C.c_int32),
+                ("status", C.c_int32)]
 
 
 class GenStats(C.Structure):
@@ -80,6 +92,10 @@ SYMBOLS = {
                                                       C.POINTER(_VP), C.POINTER(_VP), C.POINTER(GenStats), _VP]),
     "ttx_greedy_speculative_generate_pool": (C.c_int, [C.POINTER(_VP), _I, _VP, _I, _I, C.POINTER(C.c_int32), _I,
                                                       C.POINTER(GenParams), _VP, _VP, _VP, C.POINTER(GenStats), _VP]),
+    "ttx_beam_speculative_generate": (C.c_int, [_VP, _VP, _I, _I, C.POINTER(BeamParams), _VP, C.POINTER(BeamStats), _VP]),
+    "ttx_beam_speculative_generate_many": (C.c_int, [C.POINTER(_VP), _I, _I, C.POINTER(_VP), C.POINTER(C.c_int),
+                                                    C.POINTER(C.c_int), C.POINTER(BeamParams), C.POINTER(_VP),
+                                                    C.POINTER(BeamStats), _VP]),
     "ttx_nucleus_mask": (C.c_int, [_VP, _VP, _I, _I, C.c_float, _I, C.c_float, _VP, _VP]),
     "ttx_accepted_lengths": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _I, _VP, _VP]),
     "ttx_ragged_topk": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
@@ -139,7 +155,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if handle.ttx_abi_version() != 2:
+    if handle.ttx_abi_version() != 3:
         raise RuntimeError("libttx_hip.so ABI version mismatch")
     _lib = handle
     return _lib

@@ -277,6 +277,10 @@ struct ttx_session {
   Buf snap_logits, snap_act, snap_front, snap_gen, snap_state;
   int snap_B = 0, snap_rps = 0, snap_gen_ld = 0, snap_step = 0;
   Buf leaf_score, leaf_tok, leaf_cnt, beam_summary;
+  // native beam-speculative loop
+  Buf bs_cand_next, bs_len_next, bs_fin_next, bs_logp_next, bs_len, bs_fin, bs_active, bs_logp, bs_per_cand, bs_best_n, bs_best_slot,
+      bs_chosen, bs_parent, bs_parent_draft, bs_mark, bs_drafts_src, bs_cnt;
+  BeamHost* beam_host = nullptr;   // pinned + device-mapped, written by k_bs_publish
   // tree (beam) decoding
   Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of, t_len, t_parent, t_parent_draft, t_active;
   struct { int B = 0, Ls = 0, max_cand = 0, max_len = 0, N = 0, D = 0, Lc = 0, gen_ld = 0, cur = 0, prev_N = 1, prev_D = 0, steps = 0; } tree;
@@ -326,7 +330,9 @@ struct ttx_session {
                                  &pool_io, &memkv_new, &valid_new, &drafts_new, &tk[0], &tk[1], &tv[0], &tv[1],
                                  &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active, &dbg_gemm,
                                  &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state, &leaf_score, &leaf_tok, &leaf_cnt,
-                                 &beam_summary}) { b->owner_gen = &alloc_generation; all.push_back(b); } }
+                                 &beam_summary, &bs_cand_next, &bs_len_next, &bs_fin_next, &bs_logp_next, &bs_len, &bs_fin, &bs_active,
+                                 &bs_logp, &bs_per_cand, &bs_best_n, &bs_best_slot, &bs_chosen, &bs_parent, &bs_parent_draft, &bs_mark,
+                                 &bs_drafts_src, &bs_cnt}) { b->owner_gen = &alloc_generation; all.push_back(b); } }
 };
 
 // Growing a workspace must not stall the other sessions' streams: hipFree waits for the whole device, so the old
@@ -419,6 +425,7 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
   for (Buf* b : s->all)
     if (b->p) (void)hipFree(b->p);
   if (s->host_info) (void)hipHostFree(s->host_info);
+  if (s->beam_host) (void)hipHostFree(s->beam_host);
   s->drop_graphs();
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   if (s->ev_done) (void)hipEventDestroy(s->ev_done);
@@ -1862,21 +1869,370 @@ extern "C" int ttx_beam_expand(ttx_session* s, const float* d_cl, const int64_t*
                     s->leaf_cnt.as<int>()};
   hipLaunchKernelGGL(k_beam_leaves, dim3(n_cand), dim3(256), (size_t)2 * dl1 * 4, st, la);
   HIP_TRY(hipGetLastError());
-  BeamSelectArgs sa{s->leaf_score.as<float>(), s->leaf_tok.as<int>(), s->leaf_cnt.as<int>(), d_cand, width, d_len, d_chosen,
-                    d_chosen_slot, d_finished, B, beam, dl, K, pad, eos, d_new_cand, d_new_logp, d_parent, d_parent_draft, d_mark,
-                    s->beam_summary.as<int>()};
+  BeamSelectArgs<int64_t> sa{s->leaf_score.as<float>(), s->leaf_tok.as<int>(), s->leaf_cnt.as<int>(), d_cand, width, width, width,
+                             d_len, d_chosen, d_chosen_slot, d_finished, B, beam, dl, K, pad, eos, d_new_cand, d_new_logp, d_parent,
+                             d_parent_draft, d_mark, s->beam_summary.as<int>(), nullptr, nullptr};
   const size_t lds = 2 * L * 4;
   static bool attr = false;
   if (lds > 64 * 1024 && !attr) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_beam_select), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_beam_select<int64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr = true;
   }
-  hipLaunchKernelGGL(k_beam_select, dim3(B), dim3(256), lds, st, sa);
+  hipLaunchKernelGGL(k_beam_select<int64_t>, dim3(B), dim3(256), lds, st, sa);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(h_summary, s->beam_summary.p, 5 * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (h_summary[4]) return fail(TTX_ERR_REFERENCE, "a source has fewer candidate leaves than n_best (the reference asserts here, speculative_decoding.py:195)");
   return TTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Beam-search speculative decoding, whole loop native (speculative_decoding.py:428-598 all drafts, :600-845 smart drafts).
+// Device kernels of one iteration: see "Native beam-speculative loop" in ttx_kernels.hip.h.  The host keeps the loop
+// scalars of the reference (draft_len, width, num_of_empty_columns, postn_after_the_last_meaning_token, possible_draft_len)
+// and learns {candidates holding EOS, longest new row, accepted-token marks} of every iteration from pinned words the
+// last kernel of the iteration publishes — no stream synchronisation inside the loop.
+struct BeamJob {
+  ttx_session* s = nullptr;
+  hipStream_t st = nullptr;
+  ttx_beam_params p{};
+  int B = 0, Ls = 0, K = 0, N = 0, D0 = 0, n_lib = 0, lib_ld = 0, max_cand = 0, gen_ld = 0, Lc = 0;
+  bool smart = false;
+  // loop scalars
+  int n_cand = 0, beam = 1, dl = 0, width = 1, empty_cols = 0, after_last = 1, room = 0, prev_dl = 0, cur = 0;
+  int launched = 0;
+  int phase = 0;             // 0 idle, 1 iteration in flight, 2 finishing, 3 done
+  bool any_iteration = false;
+  ttx_beam_stats acc{};
+  int64_t* d_out = nullptr;
+  ttx_beam_stats* stats = nullptr;
+  int rc = TTX_OK;
+  std::chrono::steady_clock::time_point last_progress = std::chrono::steady_clock::now();
+  unsigned idle_spins = 0;
+};
+
+static int beam_validate(const ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_beam_params* p, const int64_t* d_out) {
+  if (!s || !d_src || !p || !d_out || B <= 0 || Ls <= 1) return fail(TTX_ERR_INVALID, "bad argument to ttx_beam_speculative_generate");
+  const ttx_config& c = s->m->cfg;
+  if (p->n_best < 1 || p->n_best > NUC_MAX_KEEP) return fail(TTX_ERR_INVALID, "n_best must be in [1,32]");
+  if (c.vocab_size > 64 * NUC_VPL) return fail(TTX_ERR_INVALID, "vocabulary larger than 1024");
+  if (p->n_drafts <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
+  if (p->n_drafts > BS_MAX_SLOTS) return fail(TTX_ERR_INVALID, "n_drafts beyond the 64 draft slots of the bookkeeping kernels");
+  if (p->pad_token == p->replace_token || p->eos_token == p->replace_token || p->eos_token == p->pad_token)
+    return fail(TTX_ERR_REFERENCE, "pad, eos and replace tokens must be pairwise different");
+  if (p->pad_token != c.pad_token) return fail(TTX_ERR_INVALID, "generator pad token differs from the model's");
+  if (p->max_len < 3)          // possible_draft_len = max_len - 2 < 1: the reference's loop never runs and it returns an unbound name
+    return fail(TTX_ERR_REFERENCE, "max_len < 3: the reference's loop body never runs (UnboundLocalError: new_candidates)");
+  if (p->smart_drafts_mode && Ls - 5 <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
+  const int D = clamp_draft_len(p->draft_len, 5, 200);
+  if (p->max_len + D + 3 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len + draft_len exceeds the positional table");
+  return TTX_OK;
+}
+
+static int beam_start(BeamJob& j, ttx_session* s, hipStream_t st, const int64_t* d_src, int B, int Ls, const ttx_beam_params* p,
+                      int64_t* d_out, ttx_beam_stats* stats) {
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
+  j = BeamJob{};
+  j.s = s; j.st = st; j.p = *p; j.B = B; j.Ls = Ls; j.K = p->n_best; j.N = p->n_drafts; j.smart = p->smart_drafts_mode != 0;
+  j.d_out = d_out; j.stats = stats;
+  const int Dreq = clamp_draft_len(p->draft_len, 5, 200);            // :278-284
+  // all drafts: make_drafts(src[:, 1:], draft_len, N, 5, 200) -> D0 = draft_len; smart: windows of draft_len + 1 tokens
+  // (clamped again by make_drafts, drafting.py:48) whose first token is the key -> D0 = that - 1
+  j.lib_ld = clamp_draft_len(Dreq + 1, 5, 200);
+  j.D0 = j.smart ? j.lib_ld - 1 : Dreq;
+  j.n_lib = Ls - 5;
+  j.max_cand = B * j.K;
+  j.gen_ld = p->max_len + j.D0 + 2;
+  j.Lc = p->max_len + j.D0 + 2;
+  const size_t MC = (size_t)j.max_cand;
+  const size_t Mmax = MC * step_rps(j.N, j.D0);
+  int rc = TTX_OK;
+  auto need = [&](Buf& b, size_t bytes) { if (rc == TTX_OK) rc = ensure(b, bytes, st); };
+  need(s->tok_src, (size_t)B * Ls * 4); need(s->src_valid, (size_t)B * Ls); need(s->memory, (size_t)B * Ls * d * 4);
+  need(s->memkv, (size_t)B * Ls * Ld * 2 * d * 4);
+  need(s->drafts, MC * j.N * std::max(j.D0, 1) * 4);
+  need(s->gen, MC * j.gen_ld * 4); need(s->front, MC * 4); need(s->act_idx, MC * 4);
+  need(s->pred, Mmax * 4); need(s->state, sizeof(DecState)); need(s->logits, Mmax * V * 4);
+  for (int i = 0; i < 2; ++i) { need(s->tk[i], (size_t)Ld * MC * j.Lc * d * 4); need(s->tv[i], (size_t)Ld * MC * j.Lc * d * 4); }
+  need(s->t_prev_len, MC * 4); need(s->t_slot_of, MC * 4); need(s->t_src_of, MC * 4);
+  need(s->bs_cand_next, MC * j.gen_ld * 8); need(s->bs_len_next, MC * 4); need(s->bs_fin_next, MC); need(s->bs_logp_next, MC * 4);
+  need(s->bs_len, MC * 4); need(s->bs_fin, MC); need(s->bs_active, MC); need(s->bs_logp, MC * 4); need(s->bs_per_cand, MC * 4);
+  need(s->bs_best_n, MC * 4); need(s->bs_best_slot, MC * 4); need(s->bs_chosen, MC * std::max(j.D0, 1) * 8);
+  need(s->bs_parent, MC * 4); need(s->bs_parent_draft, MC * 4); need(s->bs_mark, MC * 4);
+  need(s->bs_drafts_src, (size_t)B * (j.smart ? (size_t)j.n_lib * j.lib_ld : (size_t)j.N * j.D0) * 4);
+  need(s->bs_cnt, sizeof(BeamCounters));
+  const size_t dl1 = (size_t)j.D0 + 1;
+  need(s->leaf_score, MC * dl1 * j.K * 4); need(s->leaf_tok, MC * dl1 * j.K * 4); need(s->leaf_cnt, MC * dl1 * 4);
+  need(s->beam_summary, 8 * 4);
+  const size_t Macts = std::max(Mmax, (size_t)B * Ls);
+  if (rc == TTX_OK) rc = ensure_acts(s, st, Macts, 1);
+  need(s->qkv, std::max((size_t)Ld * Mmax, (size_t)B * Ls) * 3 * d * 4);
+  need(s->slab, sizeof(float) * 16 * Macts * d);
+  s->graphs_current();
+  TTX_TRY(rc);
+  if ((size_t)j.K * dl1 > 1023 || 2 * (size_t)j.K * dl1 * j.K * 4 > 150 * 1024)
+    return fail(TTX_ERR_INVALID, "too many leaves per source for the selection kernel's LDS image");
+  if (!s->beam_host) {
+    if (hipHostMalloc((void**)&s->beam_host, sizeof(BeamHost), hipHostMallocMapped) != hipSuccess)
+      return fail(TTX_ERR_NOMEM, "hipHostMalloc failed");
+  }
+  std::memset(s->beam_host, 0, sizeof(BeamHost));
+
+  // encoder + cross K/V once per source (:439 / :626); drafts (:430) or the draft library (:603-615)
+  TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
+  TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));
+  TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv.as<float>(),
+                      Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0));
+  if (j.smart)
+    TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls, 0, B, Ls, j.n_lib, j.lib_ld, p->eos_token, p->pad_token,
+                                    p->replace_token, s->bs_drafts_src.as<int>()));
+  else
+    TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls, 1, B, Ls - 1, j.N, j.D0, p->eos_token, p->pad_token,
+                                    p->replace_token, s->bs_drafts_src.as<int>()));
+  hipLaunchKernelGGL(k_bs_init, dim3(64), dim3(256), 0, st, s->bs_cand_next.as<int64_t>(), j.gen_ld, s->bs_len_next.as<int>(),
+                     s->bs_fin_next.as<uint8_t>(), s->bs_logp_next.as<float>(), s->bs_parent.as<int>(), s->bs_parent_draft.as<int>(),
+                     j.max_cand, B, p->bos_token, p->pad_token, s->bs_cnt.as<BeamCounters>());
+  HIP_TRY(hipGetLastError());
+  // candidate c of an iteration belongs to source c / beam: the tree kernels read the map from t_src_of, filled per iteration
+  j.n_cand = B; j.beam = 1; j.dl = j.D0; j.width = 1; j.empty_cols = 0; j.after_last = 1;
+  j.room = p->max_len - j.after_last - 1;
+  j.cur = 0; j.prev_dl = j.D0;
+  j.phase = 1;
+  return TTX_OK;
+}
+
+__global__ void k_bs_src_of(int* src_of, int n, int beam) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) src_of[i] = i / beam;
+}
+
+// Enqueue one iteration (the loop condition of :464 / :652 was checked by the caller).
+static int beam_launch_iter(BeamJob& j) {
+  ttx_session* s = j.s;
+  hipStream_t st = j.st;
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
+  j.dl = std::min(j.room, j.dl);                                   // :476
+  const int grow = j.dl + 1 - j.empty_cols;
+  if (grow > 0) j.width += grow;
+  const int dl = j.dl, MC = j.max_cand;
+  const long long cache_seq = (long long)j.Lc * d, cache_layer = (long long)MC * cache_seq;
+  BeamPrepArgs pa{};
+  pa.cand_next = s->bs_cand_next.as<int64_t>(); pa.ld = j.gen_ld; pa.len_next = s->bs_len_next.as<int>();
+  pa.fin_next = s->bs_fin_next.as<uint8_t>(); pa.logp_next = s->bs_logp_next.as<float>();
+  pa.n_cand = j.n_cand; pa.beam = j.beam; pa.dl = dl; pa.N = j.N; pa.pad = j.p.pad_token;
+  pa.smart = j.smart ? 1 : 0; pa.n_lib = j.n_lib; pa.lib_ld = j.lib_ld;
+  pa.drafts_all = s->bs_drafts_src.as<int>(); pa.D0 = j.D0; pa.lib = s->bs_drafts_src.as<int>();
+  pa.gen = s->gen.as<int>(); pa.front = s->front.as<int>(); pa.len = s->bs_len.as<int>(); pa.active = s->bs_active.as<uint8_t>();
+  pa.finished = s->bs_fin.as<uint8_t>(); pa.logp = s->bs_logp.as<float>(); pa.per_cand = s->bs_per_cand.as<int>();
+  pa.drafts32 = s->drafts.as<int>();
+  hipLaunchKernelGGL(k_bs_prep, dim3(MC), dim3(256), 0, st, pa);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_bs_src_of, dim3(cdiv(MC, 256)), dim3(256), 0, st, s->t_src_of.as<int>(), MC, j.beam);
+  HIP_TRY(hipGetLastError());
+  const int nxt = j.cur ^ 1;
+  if (j.launched > 0) {
+    TreeCacheArgs ca{};
+    ca.len = s->bs_len.as<int>(); ca.parent = s->bs_parent.as<int>(); ca.parent_draft = s->bs_parent_draft.as<int>();
+    ca.prev_len = s->t_prev_len.as<int>(); ca.active = s->bs_active.as<uint8_t>();
+    ca.k_old = s->tk[j.cur].as<float>(); ca.v_old = s->tv[j.cur].as<float>();
+    ca.k_new = s->tk[nxt].as<float>(); ca.v_new = s->tv[nxt].as<float>();
+    ca.cache_layer_stride = cache_layer; ca.cache_seq_stride = cache_seq;
+    ca.qkv_prev = s->qkv.as<float>();
+    ca.qkv_layer_stride = (long long)MC * step_rps(j.N, j.prev_dl) * 3 * d;
+    ca.prev_slot_of = s->t_slot_of.as<int>(); ca.prev_N = j.N; ca.prev_D = j.prev_dl; ca.d = d;
+    hipLaunchKernelGGL(k_tree_cache, dim3(MC, Ld), dim3(256), 0, st, ca);
+    HIP_TRY(hipGetLastError());
+  }
+  j.cur = nxt;
+  BeamListArgs la{};
+  la.active = s->bs_active.as<uint8_t>(); la.per_cand = s->bs_per_cand.as<int>(); la.len = s->bs_len.as<int>();
+  la.n_cand = j.n_cand; la.N = j.N; la.dl = dl;
+  la.act_idx = s->act_idx.as<int>(); la.slot_of = s->t_slot_of.as<int>(); la.prev_len = s->t_prev_len.as<int>();
+  la.st = s->state.as<DecState>(); la.cnt = s->bs_cnt.as<BeamCounters>(); la.summary = s->beam_summary.as<int>();
+  hipLaunchKernelGGL(k_bs_list, dim3(1), dim3(256), 0, st, la);
+  HIP_TRY(hipGetLastError());
+  // the verify step: D+1 new positions per (running candidate, draft slot) on the candidate's KV cache
+  StepCtx k{};
+  k.B = MC; k.Ls = j.Ls; k.N = j.N; k.D = dl; k.Lc = j.Lc; k.gen_ld = j.gen_ld; k.max_len = j.p.max_len;
+  k.kcache = s->tk[j.cur].as<float>(); k.vcache = s->tv[j.cur].as<float>(); k.src_of = s->t_src_of.as<int>(); k.want_argmax = false;
+  {
+    struct PolicyScope {          // few hundred step rows: the small-batch GEMM policy, as ttx_tree_step
+      ttx_session* s; int g3, ps, fs, bt;
+      explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles) {
+        if (!s->tree_big_policy) { s->gemm3_max_n = 768; s->proj_split = 4; s->ffn2_split = 8; s->big_min_tiles = 0; }
+      }
+      ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; }
+    } scope(s);
+    TTX_TRY(run_step(s, st, k, std::min(j.p.max_len, ((j.width + 63) / 64) * 64)));
+  }
+  BeamAcceptArgs aa{};
+  aa.logits = s->logits.as<float>(); aa.V = V; aa.finished = s->bs_fin.as<uint8_t>(); aa.slot_of = s->t_slot_of.as<int>();
+  aa.per_cand = s->bs_per_cand.as<int>(); aa.drafts32 = s->drafts.as<int>(); aa.cnt = s->bs_cnt.as<BeamCounters>();
+  aa.n_cand = j.n_cand; aa.N = j.N; aa.dl = dl; aa.K = j.K; aa.smart = j.smart ? 1 : 0; aa.nucleus = 0.9975f;
+  aa.best_n = s->bs_best_n.as<int>(); aa.best_slot = s->bs_best_slot.as<int>(); aa.chosen = s->bs_chosen.as<int64_t>();
+  hipLaunchKernelGGL(k_bs_accept, dim3(MC), dim3(256), 0, st, aa);
+  HIP_TRY(hipGetLastError());
+  BeamLeaves2Args le{};
+  le.logits = s->logits.as<float>(); le.V = V; le.finished = s->bs_fin.as<uint8_t>(); le.slot_of = s->t_slot_of.as<int>();
+  le.best_n = s->bs_best_n.as<int>(); le.best_slot = s->bs_best_slot.as<int>(); le.drafts32 = s->drafts.as<int>();
+  le.logp = s->bs_logp.as<float>(); le.n_cand = j.n_cand; le.N = j.N; le.dl = dl; le.K = j.K; le.bos = j.p.bos_token; le.pad = j.p.pad_token;
+  le.leaf_score = s->leaf_score.as<float>(); le.leaf_tok = s->leaf_tok.as<int>(); le.leaf_cnt = s->leaf_cnt.as<int>();
+  hipLaunchKernelGGL(k_bs_leaves, dim3(MC), dim3(256), (size_t)2 * (dl + 1) * 4, st, le);
+  HIP_TRY(hipGetLastError());
+  BeamSelectArgs<int> sa{s->leaf_score.as<float>(), s->leaf_tok.as<int>(), s->leaf_cnt.as<int>(), s->gen.as<int>(), j.gen_ld, j.gen_ld,
+                         j.gen_ld, s->bs_len.as<int>(), s->bs_chosen.as<int64_t>(), s->bs_best_slot.as<int>(), s->bs_fin.as<uint8_t>(),
+                         j.B, j.beam, dl, j.K, j.p.pad_token, j.p.eos_token, s->bs_cand_next.as<int64_t>(), s->bs_logp_next.as<float>(),
+                         s->bs_parent.as<int>(), s->bs_parent_draft.as<int>(), s->bs_mark.as<int>(), s->beam_summary.as<int>(),
+                         s->bs_len_next.as<int>(), s->bs_fin_next.as<uint8_t>()};
+  const size_t lds = 2 * (size_t)j.beam * (dl + 1) * j.K * 4;
+  static bool attr = false;
+  if (lds > 64 * 1024 && !attr) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_beam_select<int>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_beam_select<int>, dim3(j.B), dim3(256), lds, st, sa);
+  HIP_TRY(hipGetLastError());
+  BeamHost* dev_host = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&dev_host, (void*)s->beam_host, 0));
+  ++j.launched;
+  hipLaunchKernelGGL(k_bs_publish, dim3(1), dim3(64), 0, st, s->beam_summary.as<int>(), dev_host, j.launched);
+  HIP_TRY(hipGetLastError());
+  j.prev_dl = dl;
+  j.any_iteration = true;
+  j.last_progress = std::chrono::steady_clock::now();
+  j.idle_spins = 0;
+  return TTX_OK;
+}
+
+// The published summary of the iteration just finished -> the reference's loop scalars (:578-598).  Returns true when the
+// loop goes on.
+static bool beam_after_iter(BeamJob& j) {
+  const volatile int* sm = j.s->beam_host->summary;
+  const int n_eos = sm[0], min_pad = sm[1], acc_sum = sm[2], acc_cnt = sm[3], err = sm[4];
+  if (err) {
+    j.rc = fail(TTX_ERR_REFERENCE, "a source has fewer candidate leaves than n_best (the reference asserts here, speculative_decoding.py:195)");
+    return false;
+  }
+  j.acc.accepted_tokens += acc_sum;
+  j.acc.produced_non_pad_tokens += acc_sum + acc_cnt;
+  j.n_cand = j.B * j.K;
+  j.beam = j.K;
+  if (n_eos == j.B * j.K) return false;                             // :586
+  const int max_real = j.gen_ld - min_pad;                          // longest new row
+  j.empty_cols = j.width - max_real;                                // min over rows of their PAD count (:592)
+  j.after_last = j.width - j.empty_cols;
+  j.room = j.p.max_len - j.after_last - 1;
+  if (!(j.room >= 1 && j.after_last <= j.p.max_len)) return false;  // :464
+  if (j.p.max_steps > 0 && j.launched >= j.p.max_steps) {
+    j.rc = fail(TTX_ERR_INVALID, "beam-speculative loop exceeded max_steps (non-terminating input)");
+    return false;
+  }
+  return true;
+}
+
+static int beam_finish_enqueue(BeamJob& j) {
+  ttx_session* s = j.s;
+  // new_candidates.reshape(b_size, n_best, -1): rows of the last selection, `width` columns
+  if (j.width > j.p.max_len) return fail(TTX_ERR_HIP, "beam-speculative loop: result wider than max_len (internal error)");
+  HIP_TRY(hipMemcpy2DAsync(j.d_out, (size_t)j.p.max_len * 8, s->bs_cand_next.p, (size_t)j.gen_ld * 8, (size_t)j.width * 8,
+                           (size_t)j.B * j.K, hipMemcpyDeviceToDevice, j.st));
+  HIP_TRY(hipMemcpyAsync(s->host_state, s->bs_cnt.p, sizeof(BeamCounters), hipMemcpyDeviceToHost, j.st));
+  HIP_TRY(hipEventRecord(s->ev_done, j.st));
+  j.phase = 2;
+  return TTX_OK;
+}
+
+static void beam_collect(BeamJob& j) {
+  const BeamCounters* cn = reinterpret_cast<const BeamCounters*>(j.s->host_state);
+  j.acc.model_calls = cn->model_calls;
+  j.acc.input_lines = cn->input_lines;
+  j.acc.running_rows = cn->running_rows;
+  j.acc.out_width = j.width;
+  j.acc.status = j.rc;
+  if (j.stats) *j.stats = j.acc;
+  j.phase = 3;
+}
+
+static_assert(sizeof(BeamCounters) <= sizeof(DecState), "the pinned read-back buffer is sized for DecState");
+
+extern "C" int ttx_beam_speculative_generate_many(ttx_session** sessions, int n_sessions, int n_batches, const int64_t* const* d_src,
+                                                  const int* B, const int* Ls, const ttx_beam_params* p, int64_t* const* d_out,
+                                                  ttx_beam_stats* stats, void* stream) {
+  if (!sessions || n_sessions <= 0 || n_batches < 0 || !d_src || !B || !Ls || !p || !d_out || !stats)
+    return fail(TTX_ERR_INVALID, "bad argument to ttx_beam_speculative_generate_many");
+  for (int i = 0; i < n_sessions; ++i) { if (!sessions[i]) return fail(TTX_ERR_INVALID, "null session"); TTX_TRY(session_alive(sessions[i])); }
+  for (int i = 0; i < n_batches; ++i) TTX_TRY(beam_validate(sessions[0], d_src[i], B[i], Ls[i], p, d_out[i]));
+  if (n_batches == 0) return TTX_OK;
+  HIP_TRY(hipSetDevice(sessions[0]->m->device));
+  release_retired();
+  EventGuard ready;
+  HIP_TRY(hipEventCreateWithFlags(&ready.e, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ready.e, (hipStream_t)stream));
+  const int n_jobs = std::min(n_sessions, n_batches);
+  for (int i = 0; i < n_jobs; ++i) {
+    if (!sessions[i]->own_stream) HIP_TRY(hipStreamCreateWithFlags(&sessions[i]->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamWaitEvent(sessions[i]->own_stream, ready.e, 0));
+  }
+  std::vector<BeamJob> jobs(n_jobs);
+  std::vector<int> batch_of(n_jobs, -1);
+  int next = 0, done = 0, rc_final = TTX_OK;
+  bool hung = false;
+  auto fail_all = [&](int rc) { if (rc_final == TTX_OK) rc_final = rc; done = n_batches; };
+  while (done < n_batches) {
+    bool progressed = false;
+    for (int i = 0; i < n_jobs && done < n_batches; ++i) {
+      BeamJob& j = jobs[i];
+      ttx_session* s = sessions[i];
+      if (j.phase == 0 || j.phase == 3) {
+        if (next >= n_batches) continue;
+        const int b = next++;
+        batch_of[i] = b;
+        int rc = beam_start(j, s, s->own_stream, d_src[b], B[b], Ls[b], p, d_out[b], &stats[b]);
+        if (rc == TTX_OK) rc = beam_launch_iter(j);                 // max_len >= 3: the first iteration always runs
+        if (rc != TTX_OK) { fail_all(rc); break; }
+        progressed = true;
+      } else if (j.phase == 1) {
+        if (s->beam_host->steps_done < j.launched) {               // the iteration in flight has not published yet
+          if ((++j.idle_spins & 0xffff) == 0 && watchdog_expired(j.last_progress)) { hung = true; fail_all(session_hung(s)); break; }
+          continue;
+        }
+        int rc = TTX_OK;
+        if (beam_after_iter(j)) rc = beam_launch_iter(j);
+        else rc = beam_finish_enqueue(j);
+        if (rc != TTX_OK) { fail_all(rc); break; }
+        progressed = true;
+      } else if (j.phase == 2) {
+        if (hipEventQuery(s->ev_done) == hipSuccess) {
+          beam_collect(j);
+          if (j.rc != TTX_OK && rc_final == TTX_OK) rc_final = j.rc;
+          ++done;
+          progressed = true;
+        }
+      }
+    }
+    if (!progressed) __builtin_ia32_pause();
+  }
+  if (hung) {
+    for (int i = 0; i < n_jobs; ++i) sessions[i]->dead = true;
+  } else {
+    for (int i = 0; i < n_jobs; ++i) (void)hipStreamSynchronize(sessions[i]->own_stream);
+  }
+  return rc_final;
+}
+
+extern "C" int ttx_beam_speculative_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_beam_params* p,
+                                             int64_t* d_out, ttx_beam_stats* stats, void* stream) {
+  ttx_beam_stats local{};
+  const int64_t* srcs[1] = {d_src};
+  int64_t* outs[1] = {d_out};
+  ttx_session* ss[1] = {s};
+  if (!s) return fail(TTX_ERR_INVALID, "null session");
+  const int rc = ttx_beam_speculative_generate_many(ss, 1, 1, srcs, &B, &Ls, p, outs, stats ? stats : &local, stream);
+  return rc;
 }
 
 // Parity instrumentation: the verify step selected by ttx_gen_params.want_logits (1-based step number) of the most

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "ttx_select.h"
 
 namespace ttx {
 
@@ -2311,49 +2312,50 @@ struct BeamLeavesArgs {
   float* leaf_score; int* leaf_tok; int* leaf_cnt;   // [n_cand, dl+1, K], [n_cand, dl+1, K], [n_cand, dl+1]
 };
 
-__global__ __launch_bounds__(256) void k_beam_leaves(BeamLeavesArgs a) {
-  extern __shared__ float lp_kept[];          // [dl+1] log-softmax of the kept (chosen) token at every position
-  const int c = blockIdx.x;
+// Core of the leaf enumeration for one candidate `c` (the whole workgroup): `rowp(p)` = logits row of position p along
+// the candidate's chosen draft, `chosen(p)` = its p-th draft token.
+template <class RowPtr, class Chosen>
+__device__ __forceinline__ void beam_leaves_core(int c, int nacc, float root, int dl, int V, int K, int bos, RowPtr rowp, Chosen chosen,
+                                                 float* leaf_score, int* leaf_tok, int* leaf_cnt, float* lp_kept) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int dl1 = a.dl + 1;
-  const int nacc = (int)a.best_n[c];
+  const int dl1 = dl + 1;
   float* run = lp_kept + dl1;                 // [dl+1] sequential prefix sums
   // pass 1: per position softmax statistics, kept-token log-prob, and the surviving top-K (unsorted ranks)
   for (int p = wave; p < dl1; p += 4) {
-    const float* row = a.cl + ((size_t)c * dl1 + p) * a.V;
+    const float* row = rowp(p);
     int ki[NUC_MAX_KEEP];
     float kv[NUC_MAX_KEEP];
     int nk = 0;
     float m = -INFINITY, z = 0.f;
     if (p <= nacc) {
-      nucleus_select(row, a.V, 20.0f, a.K, lane, ki, kv, nk);
+      nucleus_select(row, V, 20.0f, K, lane, ki, kv, nk);
       float v[NUC_VPL];
 #pragma unroll
-      for (int i = 0; i < NUC_VPL; ++i) { const int col = lane + 64 * i; v[i] = col < a.V ? row[col] : -INFINITY; m = fmaxf(m, v[i]); }
+      for (int i = 0; i < NUC_VPL; ++i) { const int col = lane + 64 * i; v[i] = col < V ? row[col] : -INFINITY; m = fmaxf(m, v[i]); }
       m = wave_max(m);
 #pragma unroll
-      for (int i = 0; i < NUC_VPL; ++i) z += (lane + 64 * i < a.V) ? expf(v[i] - m) : 0.f;
+      for (int i = 0; i < NUC_VPL; ++i) z += (lane + 64 * i < V) ? expf(v[i] - m) : 0.f;
       z = wave_sum(z);
     }
     if (lane == 0) {
       int cnt = 0;
       if (p <= nacc) {
-        const int excl = (p < nacc) ? (int)a.chosen[(size_t)c * a.dl + p] : ((p < a.dl) ? a.bos : -1);
+        const int excl = (p < nacc) ? chosen(p) : ((p < dl) ? bos : -1);
         // ascending token id (insertion sort of <= 32 entries), dropping excluded tokens and exact-zero logits
         for (int i = 0; i < nk; ++i) {
           if (ki[i] == excl || kv[i] == 0.0f) continue;
           int pos = cnt++;
-          float* ls = a.leaf_score + ((size_t)c * dl1 + p) * a.K;
-          int* lt = a.leaf_tok + ((size_t)c * dl1 + p) * a.K;
+          float* ls = leaf_score + ((size_t)c * dl1 + p) * K;
+          int* lt = leaf_tok + ((size_t)c * dl1 + p) * K;
           while (pos > 0 && lt[pos - 1] > ki[i]) { lt[pos] = lt[pos - 1]; ls[pos] = ls[pos - 1]; --pos; }
           lt[pos] = ki[i];
           ls[pos] = logf(expf(kv[i] - m) / z);         // log(softmax), as the reference writes it
         }
-        lp_kept[p] = (p < nacc) ? logf(expf(row[(int)a.chosen[(size_t)c * a.dl + p]] - m) / z) : 0.f;
+        lp_kept[p] = (p < nacc) ? logf(expf(row[chosen(p)] - m) / z) : 0.f;
       } else {
         lp_kept[p] = 0.f;
       }
-      a.leaf_cnt[(size_t)c * dl1 + p] = cnt;
+      leaf_cnt[(size_t)c * dl1 + p] = cnt;
     }
   }
   __syncthreads();
@@ -2362,29 +2364,42 @@ __global__ __launch_bounds__(256) void k_beam_leaves(BeamLeavesArgs a) {
     for (int p = 0; p < dl1; ++p) { run[p] = acc; acc = (p == 0) ? lp_kept[0] : acc + lp_kept[p]; }
   }
   __syncthreads();
-  const float root = a.logp[c];
-  for (int e = threadIdx.x; e < dl1 * a.K; e += blockDim.x) {
-    const int p = e / a.K, i = e % a.K;
-    if (p <= nacc && i < a.leaf_cnt[(size_t)c * dl1 + p]) {
-      float* ls = a.leaf_score + ((size_t)c * dl1 + p) * a.K + i;
+  for (int e = threadIdx.x; e < dl1 * K; e += blockDim.x) {
+    const int p = e / K, i = e % K;
+    if (p <= nacc && i < leaf_cnt[(size_t)c * dl1 + p]) {
+      float* ls = leaf_score + ((size_t)c * dl1 + p) * K + i;
       const float stepsum = (p == 0) ? *ls : run[p] + *ls;     // the torch path adds columns 0..p in order, then zeros
       *ls = root + stepsum;
     }
   }
 }
 
+__global__ __launch_bounds__(256) void k_beam_leaves(BeamLeavesArgs a) {
+  extern __shared__ float lp_kept[];          // [dl+1] log-softmax of the kept (chosen) token at every position, then [dl+1] sums
+  const int c = blockIdx.x;
+  const int dl1 = a.dl + 1;
+  beam_leaves_core(c, (int)a.best_n[c], a.logp[c], a.dl, a.V, a.K, a.bos,
+                   [&](int p) { return a.cl + ((size_t)c * dl1 + p) * a.V; },
+                   [&](int p) { return (int)a.chosen[(size_t)c * a.dl + p]; },
+                   a.leaf_score, a.leaf_tok, a.leaf_cnt, lp_kept);
+}
+
+template <typename TokT>
 struct BeamSelectArgs {
   const float* leaf_score; const int* leaf_tok; const int* leaf_cnt;
-  const int64_t* cand; int width;              // [n_cand, width] current rows (left-aligned, >= dl+1 PAD columns at the end)
+  const TokT* cand; int width;                 // [n_cand, width] current rows (left-aligned, >= dl+1 PAD columns at the end)
+  int ld_in, ld_out;                           // row strides of `cand` and `new_cand` (>= width)
   const int* len;                              // [n_cand] real tokens per row
   const int64_t* chosen; const int* chosen_slot;   // [n_cand, dl], [n_cand] draft slot of the chosen draft
   const uint8_t* finished;                     // [n_cand] row already holds EOS
   int B, beam, dl, K, pad, eos;
   int64_t* new_cand; float* new_logp; int* parent; int* parent_draft; int* mark;   // [B*K, width], [B*K] ...
   int* summary;                                // [4]: candidates with EOS, min PAD count, sum of marks >= 0, count of marks >= 0; [4] error
+  int* new_len; uint8_t* new_finished;         // optional [B*K]: real tokens of every new row / whether it holds EOS
 };
 
-__global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs a) {
+template <typename TokT>
+__global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
   extern __shared__ float sh[];                // scores [L] then codes [L] (as int)
   const int b = blockIdx.x;
   const int dl1 = a.dl + 1;
@@ -2445,10 +2460,10 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs a) {
     const int out = b * a.K + r;                // new candidate index
     const int tok = a.leaf_tok[((size_t)b * nseg + seg) * a.K + i];
     const int lc = a.len[c];
-    const int64_t* root = a.cand + (size_t)c * a.width;
-    int64_t* dst = a.new_cand + (size_t)out * a.width;
+    const TokT* root = a.cand + (size_t)c * a.ld_in;
+    int64_t* dst = a.new_cand + (size_t)out * a.ld_out;
     for (int col = threadIdx.x; col < a.width; col += blockDim.x) {
-      int64_t t = root[col];
+      int64_t t = (int64_t)root[col];
       const int j = col - lc;
       if (j >= 0 && j <= a.dl) t = (j < p) ? a.chosen[(size_t)c * a.dl + j] : (j == p ? (int64_t)tok : (int64_t)a.pad);
       dst[col] = t;
@@ -2464,6 +2479,7 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs a) {
       // PAD columns of the new row: everything after its last real token
       const int real = (tok == a.pad) ? lc + p : lc + p + 1;
       atomicMin(&a.summary[1], a.width - real);
+      if (a.new_len) { a.new_len[out] = real; a.new_finished[out] = has_eos ? 1 : 0; }
       if (!fin_root) { atomicAdd(&a.summary[2], p); atomicAdd(&a.summary[3], 1); }
       sc[sel] = -INFINITY;
       code[sel] = 0x7fffffff;
@@ -2565,6 +2581,252 @@ __global__ __launch_bounds__(256) void k_tree_logits(const float* logits, int V,
   const float* src = logits + ((size_t)slot * RPS + srow) * V;
   float* dst = out + (((size_t)c * N + n) * D1 + j) * V;
   for (int v = threadIdx.x; v < V; v += blockDim.x) dst[v] = src[v];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Native beam-speculative loop (ttx_beam_speculative_generate; speculative_decoding.py:428-598 all drafts, :600-845 smart
+// drafts).  One iteration = k_bs_prep -> k_tree_cache -> k_bs_list -> the verify step (run_step) -> k_bs_accept ->
+// k_bs_leaves -> k_beam_select<int> -> k_bs_publish.  The host knows every scalar of an iteration (candidate count, draft
+// length, logical width) from what the previous one published, so they travel as kernel arguments; only the list of
+// running candidates and the per-candidate choices live on the device.
+
+// Inclusive scan of one int per thread over a 256-thread workgroup (Hillis-Steele in LDS).
+__device__ __forceinline__ int block_scan_incl256(int v, int* s_scan) {
+  s_scan[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int u = (threadIdx.x >= off) ? s_scan[threadIdx.x - off] : 0;
+    __syncthreads();
+    s_scan[threadIdx.x] += u;
+    __syncthreads();
+  }
+  return s_scan[threadIdx.x];
+}
+
+struct BeamHost { int steps_done; int summary[5]; };     // pinned, device-mapped: written by k_bs_publish
+
+struct BeamCounters {          // device-resident sums of one generate call
+  long long model_calls, input_lines, running_rows;
+  int max_group;               // smart drafts: largest number of drafts any candidate tries in the current iteration
+  int pad_;
+};
+
+constexpr int BS_MAX_SLOTS = 64;     // draft slots per candidate (n_drafts) the bookkeeping kernels hold in LDS
+
+struct BeamPrepArgs {
+  const int64_t* cand_next; int ld;                 // rows the previous selection produced (or the <BOS> rows), [max_cand, ld]
+  const int* len_next; const uint8_t* fin_next; const float* logp_next;
+  int n_cand, beam, dl, N, pad;
+  int smart, n_lib, lib_ld;                         // smart drafts: windows per source, tokens per window (first = key token)
+  const int* drafts_all; int D0;                    // all drafts: [B, N, D0]
+  const int* lib;                                   // smart drafts: [B, n_lib, lib_ld]
+  int* gen; int* front; int* len; uint8_t* active; uint8_t* finished; float* logp; int* per_cand;
+  int* drafts32;                                    // [max_cand, N, dl]: the step's draft slots
+};
+
+// One workgroup per candidate: row -> the step's loop state, and the candidate's draft slots.  All-drafts mode: the N
+// drafts of its source (:484-500).  Smart mode (:690-738): the first `N` windows of the source's library whose first token
+// equals the candidate's last token, in library order (window 0 if there is none); unused slots repeat the first draft.
+__global__ __launch_bounds__(256) void k_bs_prep(BeamPrepArgs a) {
+  __shared__ int s_scan[256];
+  __shared__ int s_match[BS_MAX_SLOTS];
+  const int c = blockIdx.x, t = threadIdx.x;
+  if (c >= a.n_cand) {
+    if (t == 0) { a.active[c] = 0; a.per_cand[c] = 0; }
+    return;
+  }
+  const int64_t* row = a.cand_next + (size_t)c * a.ld;
+  for (int col = t; col < a.ld; col += 256) a.gen[(size_t)c * a.ld + col] = (int)row[col];
+  const int lc = a.len_next[c];
+  const int fin = a.fin_next[c];
+  if (t == 0) {
+    a.len[c] = lc; a.front[c] = lc - 1; a.finished[c] = (uint8_t)fin; a.active[c] = fin ? 0 : 1; a.logp[c] = a.logp_next[c];
+  }
+  const int b = c / a.beam;
+  int* dst = a.drafts32 + (size_t)c * a.N * a.dl;
+  if (!a.smart) {
+    const int* src = a.drafts_all + (size_t)b * a.N * a.D0;
+    for (int e = t; e < a.N * a.dl; e += 256) dst[e] = src[(e / a.dl) * a.D0 + e % a.dl];
+    if (t == 0) a.per_cand[c] = a.N;
+    return;
+  }
+  const int last = (int)row[lc - 1];
+  const int* lib = a.lib + (size_t)b * a.n_lib * a.lib_ld;
+  int running = 0;
+  for (int base = 0; base < a.n_lib && running < a.N; base += 256) {
+    const int i = base + t;
+    const int flag = (i < a.n_lib && lib[(size_t)i * a.lib_ld] == last) ? 1 : 0;
+    const int incl = block_scan_incl256(flag, s_scan);
+    const int pos = running + incl - 1;
+    if (flag && pos < a.N) s_match[pos] = i;
+    running += s_scan[255];
+    __syncthreads();
+  }
+  int count = running < a.N ? running : a.N;
+  if (count == 0) {                                   // "each line needs at least one draft" (:417)
+    if (t == 0) s_match[0] = 0;
+    count = 1;
+  }
+  __syncthreads();
+  for (int e = t; e < a.N * a.dl; e += 256) {
+    const int n = e / a.dl, j = e % a.dl;
+    dst[e] = lib[(size_t)s_match[n < count ? n : 0] * a.lib_ld + 1 + j];
+  }
+  if (t == 0) a.per_cand[c] = count;
+}
+
+struct BeamListArgs {
+  const uint8_t* active; const int* per_cand; const int* len;
+  int n_cand, N, dl;
+  int* act_idx; int* slot_of; int* prev_len; DecState* st; BeamCounters* cnt; int* summary;
+};
+
+// One workgroup: compact list of the running candidates (candidate order), the DecState the step kernels size their
+// work from, the iteration's counters, and the reset of the selection summary.
+__global__ __launch_bounds__(256) void k_bs_list(BeamListArgs a) {
+  __shared__ int s_scan[256];
+  __shared__ int s_lines, s_run, s_maxg;
+  const int t = threadIdx.x;
+  if (t == 0) { s_lines = 0; s_run = 0; s_maxg = 0; }
+  __syncthreads();
+  int before = 0;
+  for (int base = 0; base < a.n_cand; base += 256) {
+    const int c = base + t;
+    const int act = (c < a.n_cand && a.active[c]) ? 1 : 0;
+    const int incl = block_scan_incl256(act, s_scan);
+    if (c < a.n_cand) {
+      const int pc = a.per_cand[c];
+      a.slot_of[c] = act ? before + incl - 1 : -1;
+      a.prev_len[c] = a.len[c];
+      if (act) { a.act_idx[before + incl - 1] = c; atomicAdd(&s_run, pc); }
+      atomicAdd(&s_lines, pc);
+      atomicMax(&s_maxg, pc);
+    }
+    before += s_scan[255];
+    __syncthreads();
+  }
+  if (t == 0) {
+    DecState s;
+    s.n_active = before; s.r_rows = before * a.N; s.m_rows = before * step_rps(a.N, a.dl);
+    s.stop = 0; s.width = 0; s.steps = 0; s.error = 0; s.n_copy = 0;
+    s.accepted = s.produced = s.verified_positions = s.kv_prefix_positions = s.src_positions = 0;
+    *a.st = s;
+    a.cnt->model_calls += 1;
+    a.cnt->input_lines += s_lines;
+    a.cnt->running_rows += s_run;
+    a.cnt->max_group = s_maxg;
+    a.summary[0] = 0; a.summary[1] = 0x7fffffff; a.summary[2] = 0; a.summary[3] = 0; a.summary[4] = 0;
+  }
+}
+
+struct BeamAcceptArgs {
+  const float* logits; int V;                        // the step's logits, [n_active * RPS, V]
+  const uint8_t* finished; const int* slot_of; const int* per_cand; const int* drafts32;
+  const BeamCounters* cnt;
+  int n_cand, N, dl, K, smart;
+  float nucleus;
+  int* best_n; int* best_slot; int64_t* chosen;      // [max_cand], [max_cand], [max_cand, dl]
+};
+
+// One workgroup per candidate.  Accepted length of each of its drafts = leading draft tokens that are among the <= K
+// tokens inside the nucleus of their position (:539-548, :847-869; finished candidates see the artificial "35 on PAD"
+// logits, under which no draft token survives), then the best draft exactly as the reference's topk(1) picks it among
+// equal counts (ttx_select.h): over the N drafts, or in smart mode over the table padded with -1 to the longest group.
+__global__ __launch_bounds__(256) void k_bs_accept(BeamAcceptArgs a) {
+  __shared__ int s_nok[BS_MAX_SLOTS];
+  __shared__ long long s_v[BS_MAX_SLOTS];
+  __shared__ int s_ix[BS_MAX_SLOTS];
+  __shared__ int s_best;
+  const int c = blockIdx.x;
+  if (c >= a.n_cand) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pc = a.per_cand[c];
+  const int RPS = step_rps(a.N, a.dl);
+  if (a.finished[c]) {
+    for (int i = threadIdx.x; i < pc; i += 256) s_nok[i] = 0;
+  } else {
+    const float* base = a.logits + (size_t)a.slot_of[c] * RPS * a.V;
+    for (int i = wave; i < pc; i += 4) {
+      const int* dr = a.drafts32 + ((size_t)c * a.N + i) * a.dl;
+      int ok = 0;
+      for (int j = 0; j < a.dl; ++j) {
+        int ki[NUC_MAX_KEEP];
+        float kv[NUC_MAX_KEEP];
+        int nk;
+        const int srow = (j == 0) ? 0 : 1 + i * a.dl + (j - 1);
+        nucleus_select(base + (size_t)srow * a.V, a.V, a.nucleus, a.K, lane, ki, kv, nk);
+        const int tok = dr[j];
+        bool hit = false;
+        for (int q = 0; q < nk; ++q) hit |= (ki[q] == tok);
+        if (!hit) break;
+        ++ok;
+      }
+      if (lane == 0) s_nok[i] = ok;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int W = a.smart ? a.cnt->max_group : a.N;
+    for (int i = 0; i < W; ++i) s_v[i] = (i < pc) ? (long long)s_nok[i] : -1ll;
+    const int best = ttxsel::topk1_index(s_v, s_ix, W);
+    s_best = best;
+    a.best_n[c] = s_nok[best];
+    a.best_slot[c] = best;
+  }
+  __syncthreads();
+  const int best = s_best;
+  for (int j = threadIdx.x; j < a.dl; j += 256) a.chosen[(size_t)c * a.dl + j] = (int64_t)a.drafts32[((size_t)c * a.N + best) * a.dl + j];
+}
+
+struct BeamLeaves2Args {
+  const float* logits; int V;
+  const uint8_t* finished; const int* slot_of; const int* best_n; const int* best_slot; const int* drafts32; const float* logp;
+  int n_cand, N, dl, K, bos, pad;
+  float* leaf_score; int* leaf_tok; int* leaf_cnt;
+};
+
+// `sample` (:294-400) on the step's own logits rows.  A finished candidate has exactly one leaf: PAD at position 0 with
+// log-softmax(35 on PAD, 0 elsewhere)[PAD] = log(1 / (1 + (V-1) e^-35)), which is 0 in fp32.
+__global__ __launch_bounds__(256) void k_bs_leaves(BeamLeaves2Args a) {
+  extern __shared__ float lp_kept[];
+  const int c = blockIdx.x;
+  if (c >= a.n_cand) return;
+  const int dl1 = a.dl + 1;
+  if (a.finished[c]) {
+    for (int p = threadIdx.x; p < dl1; p += 256) a.leaf_cnt[(size_t)c * dl1 + p] = (p == 0) ? 1 : 0;
+    if (threadIdx.x == 0) {
+      const float z = 1.0f + (float)(a.V - 1) * expf(-35.0f);
+      a.leaf_tok[(size_t)c * dl1 * a.K] = a.pad;
+      a.leaf_score[(size_t)c * dl1 * a.K] = a.logp[c] + logf(1.0f / z);
+    }
+    return;
+  }
+  const int RPS = step_rps(a.N, a.dl);
+  const int best = a.best_slot[c];
+  const float* base = a.logits + (size_t)a.slot_of[c] * RPS * a.V;
+  const int* dr = a.drafts32 + ((size_t)c * a.N + best) * a.dl;
+  beam_leaves_core(c, a.best_n[c], a.logp[c], a.dl, a.V, a.K, a.bos,
+                   [&](int p) { return base + (size_t)((p == 0) ? 0 : 1 + best * a.dl + (p - 1)) * a.V; },
+                   [&](int p) { return dr[p]; },
+                   a.leaf_score, a.leaf_tok, a.leaf_cnt, lp_kept);
+}
+
+__global__ void k_bs_publish(const int* summary, BeamHost* host, int iter) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    for (int i = 0; i < 5; ++i) host->summary[i] = summary[i];
+    __threadfence_system();
+    host->steps_done = iter;
+    __threadfence_system();
+  }
+}
+
+// First candidates of a call: one <BOS> row per source.
+__global__ void k_bs_init(int64_t* cand_next, int ld, int* len_next, uint8_t* fin_next, float* logp_next, int* parent, int* parent_draft,
+                          int max_cand, int B, int bos, int pad, BeamCounters* cnt) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int i = tid; i < max_cand * ld; i += nth) cand_next[i] = (i % ld == 0 && i / ld < B) ? bos : pad;
+  for (int i = tid; i < max_cand; i += nth) { len_next[i] = 1; fin_next[i] = 0; logp_next[i] = 0.f; parent[i] = -1; parent_draft[i] = 0; }
+  if (tid == 0) { cnt->model_calls = 0; cnt->input_lines = 0; cnt->running_rows = 0; cnt->max_group = 0; cnt->pad_ = 0; }
 }
 
 }  // namespace ttx

@@ -619,6 +619,95 @@ class TranslationInferenceBeamSearch(_BeamSearchHost):
         super().__init__(_need_native(model), *a, **k)
 
 
-class TranslationInferenceBeamSearchSpeculative(_BeamSearchSpeculativeHost):
-    def __init__(self, model, *a, **k):
-        super().__init__(_need_native(model), *a, **k)
+class TranslationInferenceBeamSearchSpeculative:
+    """Drop-in for src/decoding/speculative_decoding.py:241-869 (both draft modes): the whole loop — candidate rows, draft
+    slots, KV-cached verify step, accepted lengths, best draft, leaf enumeration and scoring, per-source selection,
+    termination — runs in ttx_beam_speculative_generate; Python allocates the output tensor and keeps the counters."""
+
+    def __init__(self, model, max_len: int, n_best: int, draft_len: int, n_drafts: int, vocab_size: int,
+                 smart_drafts_mode: bool, pad_token: int, bos_token: int, eos_token: int, C_token: int,
+                 max_steps: int | None = None) -> None:
+        self.model = _need_native(model)
+        self.max_len, self.vocab_size = max_len, vocab_size
+        self.smart_drafts_mode = smart_drafts_mode
+        self.pad_token_idx, self.bos_token_idx, self.eos_token_idx, self.C_token_idx = pad_token, bos_token, eos_token, C_token
+        self.n_best = n_best
+        self.accepted_tokens_num = 0
+        self.model_calls_num = 0
+        self.model_input_lines_num = 0
+        self.max_drafts_num = n_drafts
+        self.n_drafts = 0
+        self.requested_drafts_num = n_drafts
+        self.produced_non_pad_tokens = 0
+        self.max_draft_len, self.min_draft_len = 200, 5
+        clamped = min(max(self.min_draft_len, draft_len), self.max_draft_len)
+        if clamped != draft_len:
+            print(f"The draft length should be in range [{self.min_draft_len}: {self.max_draft_len}], so it was changed to {clamped}")
+        self.draft_len = clamped
+        self.b_sz = 0
+        # Safety valve absent from the reference, whose loop never ends when a candidate keeps emitting PAD before any
+        # EOS; None = reference behaviour.
+        self.max_steps = max_steps
+        if vocab_size != self.model.tgt_vocab_size:
+            raise ValueError("vocab_size differs from the model's target vocabulary")
+
+    def __str__(self):
+        return (f"SpeculativeSampling decoding (n_best={self.n_best}, max_len={self.max_len}, "
+                f"max_num_of_drafts={self.max_drafts_num}, draft_len={self.draft_len})")
+
+    def _params(self) -> N.BeamParams:
+        return N.BeamParams(self.max_len, self.n_best, self.draft_len, self.requested_drafts_num, int(bool(self.smart_drafts_mode)),
+                            self.pad_token_idx, self.bos_token_idx, self.eos_token_idx, self.C_token_idx, int(self.max_steps or 0))
+
+    def _account(self, st: N.BeamStats, B: int) -> None:
+        self.model_calls_num += int(st.model_calls)
+        self.model_input_lines_num += int(st.input_lines)
+        self.b_sz += int(st.running_rows)
+        self.accepted_tokens_num += int(st.accepted_tokens)
+        self.produced_non_pad_tokens += int(st.produced_non_pad_tokens)
+        if not self.smart_drafts_mode:
+            self.n_drafts += B * self.requested_drafts_num                       # :434
+
+    @staticmethod
+    def _check(rc: int) -> None:
+        if rc == N.TTX_ERR_INVALID and "max_steps" in N.lib().ttx_last_error().decode("utf-8", "replace"):
+            raise RuntimeError("beam-speculative loop exceeded max_steps (non-terminating input)")
+        N.check(rc)
+
+    def generate(self, src: torch.Tensor) -> torch.Tensor:
+        m = self.model
+        src = src.to(m.device, torch.int64).contiguous()
+        m.check_tokens(src)
+        B, Ls = src.shape
+        out = torch.empty((B, self.n_best, self.max_len), dtype=torch.int64, device=m.device)
+        p, st = self._params(), N.BeamStats()
+        self._check(m._lib.ttx_beam_speculative_generate(m.session, src.data_ptr(), B, Ls, C.byref(p), out.data_ptr(), C.byref(st),
+                                                         m._stream()))
+        self._account(st, B)
+        return out[:, :, :int(st.out_width)].contiguous()
+
+    def generate_many(self, batches: list, in_flight: int = 4) -> list:
+        """Several batches on the GPU at once (one session + stream each; ttx_beam_speculative_generate_many); every returned
+        tensor and the counters are those of per-batch ``generate`` calls."""
+        m = self.model
+        if not batches:
+            return []
+        srcs = [b.to(m.device, torch.int64).contiguous() for b in batches]
+        for b in srcs:
+            m.check_tokens(b)
+        n = len(srcs)
+        outs = [torch.empty((s.shape[0], self.n_best, self.max_len), dtype=torch.int64, device=m.device) for s in srcs]
+        pool = m.session_pool(max(1, min(in_flight, n)))
+        sess = (C.c_void_p * len(pool))(*[q.value for q in pool])
+        src_p = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        out_p = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        Bs = (C.c_int * n)(*[s.shape[0] for s in srcs])
+        Ls = (C.c_int * n)(*[s.shape[1] for s in srcs])
+        p = self._params()
+        stats = (N.BeamStats * n)()
+        self._check(m._lib.ttx_beam_speculative_generate_many(sess, len(pool), n, src_p, Bs, Ls, C.byref(p), out_p, stats, m._stream()))
+        res = []
+        for s, o, st in zip(srcs, outs, stats):
+            self._account(st, s.shape[0])
+            res.append(o[:, :, :int(st.out_width)].contiguous())
+        return res
