@@ -37,11 +37,15 @@ BASELINE_REACTIONS_PER_S = 47.97  # BASELINE.md §1, bs=32 D=10 N=3 (reference's
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--config", choices=("c2", "c3", "c4"), default="c2",
+                    help="BASELINE.json configs[1] (greedy speculative bs=32, the headline), configs[2] (MIT beam speculative "
+                         "n_best=5 bs=4 N=7) or configs[3] (50K 6+6 beam speculative n_best=10 bs=8 N=2)")
+    ap.add_argument("--steps", type=int, default=None, help="timed batches (default 256 for c2, 32 for c3/c4)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--draft-len", type=int, default=10)
-    ap.add_argument("--n-drafts", type=int, default=3)
+    ap.add_argument("--n-drafts", type=int, default=None)
+    ap.add_argument("--smart", type=int, default=0, help="c3/c4: smart_drafts_mode of the timed run (the other mode is reported beside it)")
     ap.add_argument("--max-len", type=int, default=200)
     ap.add_argument("--train-steps", type=int, default=int(os.environ.get("TTX_TRAIN_STEPS", "1500")))
     ap.add_argument("--cpu-batches", type=int, default=3, help="batches of the workload timed on the host cores")
@@ -53,7 +57,27 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
                     help="skip the comparison passes (as-given, one at a time, event profile, CPU baseline): for rocprofv3 runs")
-    return ap.parse_args()
+    a = ap.parse_args()
+    beam = BEAM_CONFIGS.get(a.config)
+    if a.steps is None:
+        a.steps = 32 if beam else 256
+    if a.batch_size is None:
+        a.batch_size = beam["bs"] if beam else 32
+    if a.n_drafts is None:
+        a.n_drafts = beam["N"] if beam else 3
+    return a
+
+
+# BASELINE.json configs[2] / configs[3]: generator settings of the reference's own grid optimum for that batch size
+# (results_grid_search/results_product_500_beam_search_speculative_bs_4_report.txt:31 -> 7.42 reactions/s;
+#  results_retro_500_beam_search_speculative_bs_8_nbest_10_report.txt:5 -> 6.12 reactions/s; scripts/product_prediction.sh:197-198,
+#  scripts/single_step_retrosynthesis.sh:166-174; model depth configs/cfg_standard_*:90-103)
+BEAM_CONFIGS = {
+    "c3": dict(kind="mit", layers=4, bs=4, n_best=5, N=7, published=7.42,
+               name="USPTO-MIT-shaped synthetic SMILES, beam-search speculative n_best=5"),
+    "c4": dict(kind="50k", layers=6, bs=8, n_best=10, N=2, published=6.12,
+               name="USPTO-50K-shaped synthetic SMILES (retrosynthesis), beam-search speculative n_best=10"),
+}
 
 
 def usable_cores() -> int:
@@ -76,13 +100,20 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def get_weights(train_steps: int, device: str) -> dict:
-    path = os.environ.get("TTX_WEIGHTS") or f"/tmp/ttx_synth_mit_{train_steps}.pt"
-    for cand in (path, str(ROOT / ".weights_cache" / f"synth_mit_{train_steps}.pt")):   # caches written by earlier runs
+def get_weights(train_steps: int, device: str, kind: str = "mit", layers: int = 4, info: dict | None = None) -> dict:
+    """Weights for the synthetic task: a cache written by an earlier run on this box (/tmp) or shipped with the snapshot
+    (.weights_cache/, git-ignored), else trained here (set-up, untimed; `info` records which and how long it took)."""
+    path = os.environ.get("TTX_WEIGHTS" if kind == "mit" else "TTX_WEIGHTS_50K") or f"/tmp/ttx_synth_{kind}_{train_steps}.pt"
+    for cand in (path, str(ROOT / ".weights_cache" / f"synth_{kind}_{train_steps}.pt")):   # caches written by earlier runs
         if os.path.exists(cand):
+            if info is not None:
+                info.update(weights="cache", path=cand)
             return torch.load(cand, weights_only=True, map_location="cpu")
     from tools.train_synth import train
-    sd = train("mit", steps=train_steps, device=device, verbose=os.environ.get("TTX_BENCH_VERBOSE") == "1")
+    t0 = time.perf_counter()
+    sd = train(kind, steps=train_steps, n_enc=layers, n_dec=layers, device=device, verbose=os.environ.get("TTX_BENCH_VERBOSE") == "1")
+    if info is not None:
+        info.update(weights="trained in this run", train_steps=train_steps, train_seconds=round(time.perf_counter() - t0, 1))
     try:
         torch.save(sd, path)
         extra = os.environ.get("TTX_SAVE_WEIGHTS")
@@ -117,10 +148,217 @@ def flops_and_bytes(cfg: dict, stats: dict, B_total_src_tokens: int, n_batches: 
     return {"gemm_flops": float(gemm_flops), "bytes": float(bytes_total), "gemm_bytes": float(gemm_bytes)}
 
 
+def beam_work(cfg: dict, st: dict, model_calls: int, positions_key: str) -> dict:
+    """Algorithmic work of the KV-cached beam-speculative loop (SURVEY.md §8(d) formulas): GEMM FLOPs over the verified
+    positions and the encoder tokens; HBM bytes = weights once per iteration / per batch + K/V reads + K/V writes."""
+    d, F, V, Le, Ld = cfg["d"], cfg["F"], cfg["V"], cfg["Le"], cfg["Ld"]
+    pos, src_tok = st[positions_key], st["src_tokens_padded"]
+    dec_dense_per_pos = Ld * (12 * d * d + 4 * d * F) + 2 * d * V
+    enc_dense_per_tok = Le * (8 * d * d + 4 * d * F)
+    cross_kv_per_tok = Ld * 4 * d * d
+    gemm_flops = pos * dec_dense_per_pos + src_tok * (enc_dense_per_tok + cross_kv_per_tok)
+    P_e = 4 * d * d + 4 * d + 2 * d * F + F + d + 4 * d
+    P_d = 2 * (4 * d * d + 4 * d) + 2 * d * F + F + d + 6 * d
+    W_enc = 4 * (Le * P_e + 2 * d + V * d)
+    W_dec = 4 * (Ld * P_d + 2 * d + d * V + V)
+    kv_read = (st["kv_prefix_positions"] + st["src_positions"]) * 2 * d * 4 * Ld
+    kv_write = st["produced"] * 2 * d * 4 * Ld
+    bytes_total = st["batches"] * W_enc + model_calls * W_dec + kv_read + kv_write
+    dec_io = 4 * (Ld * ((d + 3 * d) + 3 * (d + d) + (d + F) + (F + 2 * d)) + (d + V))
+    enc_io = 4 * (Le * ((d + 3 * d) + (d + d) + (d + F) + (F + d)) + (d + Ld * 2 * d))
+    gemm_bytes = pos * dec_io + src_tok * enc_io + model_calls * W_dec + st["batches"] * (W_enc + 4 * Ld * 2 * d * d)
+    return {"gemm_flops": float(gemm_flops), "bytes": float(bytes_total), "gemm_bytes": float(gemm_bytes)}
+
+
+def main_beam(a):
+    """configs[2] / configs[3]: beam-search speculative decoding, whole loop native (ttx_beam_speculative_generate_many).
+    A step = one given batch; `--inflight` batches are on the GPU at once (one session + stream each); outputs and counters
+    per batch are those of one-at-a-time calls (tests/test_gpu_beam_native.py)."""
+    bc = BEAM_CONFIGS[a.config]
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and os.environ.get("TTX_SHARE_GPU") != "1":
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({n_dev} visible)")
+    local_rank = local_rank % n_dev
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(os.environ.get("TTX_DIST_BACKEND", "nccl"))
+    import translation_transformer_amd as tta
+    from tools.synth import SynthReactions, batches, PAD, BOS, EOS, C_TOK, V
+
+    setup = {}
+    sd = tta.dist.broadcast_state_dict(get_weights(a.train_steps, dev, bc["kind"], bc["layers"], setup) if rank == 0 else None, dev, dist)
+    model = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=PAD, device=local_rank)
+    cfg = {"d": model.emb_dim, "F": model.ff_dim, "V": model.tgt_vocab_size, "Le": model.num_enc_layers, "Ld": model.num_dec_layers}
+    assert cfg["Le"] == bc["layers"] and cfg["Ld"] == bc["layers"]
+    per_rank = (a.steps + a.warmup) * a.batch_size
+    src_all, _ = SynthReactions(123456, bc["kind"]).dataset(per_rank * world)
+    mine = src_all[rank * per_rank:(rank + 1) * per_rank]
+    dev_batches = [torch.from_numpy(b).to(dev) for b in batches(mine, a.batch_size)]
+    warm, timed = dev_batches[:a.warmup], dev_batches[a.warmup:]
+    K, N, D, L = bc["n_best"], a.n_drafts, a.draft_len, a.max_len
+
+    def make_gen(m, smart):
+        return tta.TranslationInferenceBeamSearchSpeculative(m, L, K, D, N, V, bool(smart), PAD, BOS, EOS, C_TOK, max_steps=4 * L)
+
+    def run(gen, bs, inflight):
+        return gen.generate_many(bs, in_flight=inflight) if inflight > 1 else [gen.generate(b) for b in bs]
+
+    smart = bool(a.smart)
+    g0 = make_gen(model, smart)
+    run(g0, (warm * a.inflight)[:max(a.inflight, len(warm))], a.inflight)     # every session of the pool sized and warm
+    log("warmup done", g0.model_calls_num, "calls")
+    gen = make_gen(model, smart)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = run(gen, timed, a.inflight)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # prediction gather (C2): hypotheses padded to max_len, one collective at the end
+    flat = torch.cat([torch.nn.functional.pad(o, (0, L - o.shape[2]), value=PAD) for o in outs])
+    gathered = tta.dist.gather_predictions(flat, world * flat.shape[0], dist)
+    if rank == 0:
+        assert gathered.shape[0] == world * flat.shape[0]
+    counted = tta.dist.sum_counters({"reactions": sum(int(b.shape[0]) for b in timed)}, dev, dist)
+    n_reactions = int(counted["reactions"])
+    top1_eos = int((flat[:, 0] == EOS).any(dim=1).sum())
+    value = n_reactions / elapsed
+    line = {
+        "metric": "reactions/sec (SMILES decoded), beam-search speculative", "value": value, "unit": "reactions/s", "n_gpus": world,
+        "steps": len(timed), "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / max(1, len(timed)), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": value / bc["published"], "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{bc['name']} bs={a.batch_size} n_drafts={N} draft_len={D} max_len={L} "
+                               f"smart_drafts_mode={smart}, d=256 8h FFN2048 {bc['layers']}+{bc['layers']} fp32, weights trained "
+                               f"{a.train_steps} steps on the synthetic task",
+                   "baseline_config": a.config, "reactions": n_reactions,
+                   "parallelism": f"test-set shards x{world}, no per-step collective", "batches_in_flight_per_gpu": a.inflight},
+        "model_calls": gen.model_calls_num, "acceptance_rate": gen.accepted_tokens_num / max(1, gen.produced_non_pad_tokens),
+        "top1_rows_with_eos_rank0": top1_eos, "rows_rank0": int(flat.shape[0]),
+        "device_ms_encode_rank0": gen.stats_total["encode_ms"], "device_ms_decode_rank0": gen.stats_total["decode_ms"],
+        "setup": setup,
+    }
+    if rank == 0:
+        st = dict(gen.stats_total, produced=gen.produced_non_pad_tokens)
+        work = beam_work(cfg, st, gen.model_calls_num, "verified_positions")
+        line["hbm_algorithmic"] = {"bytes_per_reaction": work["bytes"] / max(1, len(timed) * a.batch_size),
+                                   "achieved_GBs": work["bytes"] / elapsed / 1e9,
+                                   "frac_of_peak": work["bytes"] / elapsed / 1e9 / PEAK_HBM_GBS}
+        if not a.timed_only:
+            if a.inflight > 1:
+                g1 = make_gen(model, smart)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                seq = run(g1, timed, 1)
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+                line["one_batch_at_a_time"] = {"value": n_reactions / world / dt1, "unit": "reactions/s",
+                                               "identical_to_timed_outputs": all(torch.equal(x, y) for x, y in zip(seq, outs))
+                                               and g1.model_calls_num == gen.model_calls_num}
+            g2 = make_gen(model, not smart)
+            run(g2, warm, a.inflight)
+            g2 = make_gen(model, not smart)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            other = run(g2, timed, a.inflight)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            line["other_draft_mode"] = {"smart_drafts_mode": not smart, "value": n_reactions / world / dt2, "unit": "reactions/s",
+                                        "model_calls": g2.model_calls_num,
+                                        "top1_identical_to_timed_run": sum(int(torch.equal(x[:, 0, :min(x.shape[2], y.shape[2])],
+                                                                                           y[:, 0, :min(x.shape[2], y.shape[2])]))
+                                                                           for x, y in zip(other, outs)),
+                                        "batches": len(outs)}
+        if not a.no_profile:
+            # dominant kernel family = the fp32 MFMA GEMMs: HIP events on the launch stream around every GEMM launch of the
+            # same batches, one after the other on a profiling session (raw event-pair time)
+            import ctypes as C
+            os.environ["TTX_PROFILE_GEMM"] = "1"
+            pm = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=PAD, device=local_rank)
+            os.environ.pop("TTX_PROFILE_GEMM")
+            pg = make_gen(pm, smart)
+            for b in timed:
+                pg.generate(b)
+            ms, n, e = C.c_double(), C.c_int64(), C.c_double()
+            pm._lib.ttx_last_kernel_profile(pm.session, C.byref(ms), C.byref(n), C.byref(e))
+            gemm_ms, launches, empty_ms = ms.value, n.value, e.value
+            pst = dict(pg.stats_total, produced=pg.produced_non_pad_tokens)
+            pw = beam_work(cfg, pst, pg.model_calls_num, "verified_positions")
+            pwx = beam_work(cfg, pst, pg.model_calls_num, "executed_positions")
+            ach = pw["gemm_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            net_ms = max(1e-9, gemm_ms - launches * empty_ms)
+            line["roofline"] = {"kernel": "fp32 MFMA GEMM family of the verify step under the small-row policy (k_gemm3<KW> 32x32 K-split for "
+                                          "N <= 768, k_gemm2<NT> 64x64 for FFN1; v_mfma_f32_32x32x2_f32), every launch of the run",
+                                "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                                "traffic_note": "no PMC pass was collected for this configuration",
+                                "launches": launches, "avg_launch_us": 1e3 * gemm_ms / max(1, launches),
+                                "flops_per_launch": pw["gemm_flops"] / max(1, launches),
+                                "algorithmic_bytes_per_launch": pw["gemm_bytes"] / max(1, launches),
+                                "achieved_counting_executed_rows": pwx["gemm_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
+                                "event_pair_overhead_us": 1e3 * empty_ms,
+                                "achieved_overhead_removed": pw["gemm_flops"] / (net_ms * 1e-3) / 1e12,
+                                "gemm_share_of_device_time": gemm_ms / max(1e-9, pst["encode_ms"] + pst["decode_ms"]),
+                                "note": "one batch at a time on the profiling session: a verify step has a few hundred to ~1 700 rows, "
+                                        "so these launches are latency-bound; the fraction is what the step's GEMMs reach, not the chip"}
+            pm.close()
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle.model import OracleTransformer, config_from_state
+            from oracle.spec_beam import BeamSearchSpeculativeOracle
+            cores = usable_cores()
+            torch.set_num_threads(cores)
+            om = OracleTransformer(config_from_state(sd, 8, PAD), sd)
+            og = BeamSearchSpeculativeOracle(om, L, K, D, N, V, smart, PAD, BOS, EOS, C_TOK, max_steps=4 * L)
+            sample = timed[:max(1, a.cpu_batches if a.cpu_batches != 3 else 1)]
+            with torch.inference_mode():
+                t1 = time.perf_counter()
+                cpu_out = [og.generate(b.cpu()) for b in sample]
+                cpu_s = time.perf_counter() - t1
+            top1 = all_ranks = total = 0
+            for c_, o in zip(cpu_out, outs):
+                o = o.cpu()
+                w = max(c_.shape[2], o.shape[2])
+                c_ = torch.nn.functional.pad(c_, (0, w - c_.shape[2]), value=PAD)
+                o = torch.nn.functional.pad(o, (0, w - o.shape[2]), value=PAD)
+                top1 += int((c_[:, 0] == o[:, 0]).all(dim=1).sum())
+                all_ranks += int((c_ == o).all(dim=2).sum())
+                total += c_.shape[0] * c_.shape[1]
+            n_cpu = sum(int(b.shape[0]) for b in sample)
+            line["cpu_baseline"] = {"value": n_cpu / cpu_s, "unit": "reactions/s", "cores": cores, "kind": "port",
+                                    "sample": f"first {len(sample)} timed batch(es) = {n_cpu} reactions of the same workload, oracle/ "
+                                              f"(full-prefix recompute like the reference), torch {torch.__version__} fp32",
+                                    "seconds": cpu_s, "model_calls": og.model_calls_num}
+            line["parity"] = {"top1_rows_token_identical_to_oracle": top1, "rows_checked": n_cpu,
+                              "hypotheses_token_identical_to_oracle": all_ranks, "hypotheses_checked": total}
+        print(json.dumps(line))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     if a.timed_only:
         a.no_profile = a.no_cpu_baseline = True
+    if a.config in BEAM_CONFIGS:
+        return main_beam(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,7 +380,8 @@ def main():
     from tools.synth import SynthReactions, batches, PAD, BOS, EOS, C_TOK, V
 
     # ---- weights: rank 0 trains/loads, one RCCL broadcast of the packed fp32 blob
-    sd = tta.dist.broadcast_state_dict(get_weights(a.train_steps, dev) if rank == 0 else None, dev, dist)
+    setup = {}
+    sd = tta.dist.broadcast_state_dict(get_weights(a.train_steps, dev, info=setup) if rank == 0 else None, dev, dist)
     model = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=PAD, device=local_rank)
     cfg = {"d": model.emb_dim, "F": model.ff_dim, "V": model.tgt_vocab_size, "Le": model.num_enc_layers,
            "Ld": model.num_dec_layers}
@@ -230,6 +469,7 @@ def main():
         "model_calls": stats["model_calls"], "rows_finished_rank0": finished, "rows_rank0": int(preds.shape[0]),
         "accepted_per_step_per_row": stats["accepted_tokens"] / max(1, stats["produced_tokens"] - stats["accepted_tokens"]),
         "device_ms_encode_rank0": stats["encode_ms"], "device_ms_decode_rank0": stats["decode_ms"],
+        "setup": setup,
     }
 
     if rank == 0:

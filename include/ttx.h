@@ -175,20 +175,6 @@ int ttx_accepted_lengths(ttx_session* s, const float* d_logits, const int64_t* d
                          int n_best, int32_t* d_n_ok, void* stream);
 int ttx_ragged_topk(ttx_session* s, const float* d_score, const int32_t* d_offsets, int G, int max_group, int k,
                     float* d_top, int64_t* d_idx, void* stream);
-/* ttx_beam_expand: one iteration's candidate expansion — `sample` (speculative_decoding.py:294-400: every single-token
- *   deviation along the accepted prefix of each candidate's chosen draft, scored by cumulative log-probability), the
- *   per-source top-n_best (:573-576) and the assembly of the new candidate rows (:393-395), fused in two kernels.
- *   d_cl [n_cand,dl+1,V] logits along the chosen drafts; d_chosen int64 [n_cand,dl]; d_best_n int64 [n_cand]; d_logp [n_cand];
- *   d_cand int64 [n_cand,width] left-aligned rows with >= dl+1 trailing PAD; d_len int32 real tokens per row;
- *   d_chosen_slot int32 [n_cand]; d_finished uint8 [n_cand]; n_cand = B*beam (beam = 1 on the first iteration, else K).
- *   Outputs for the B*K survivors, best first per source: rows, log-probs, parent candidate, the parent's draft slot, and
- *   the accepted-token mark (-1 for rows that were already finished).  h_summary is a HOST int32[5]. */
-int ttx_beam_expand(ttx_session* s, const float* d_cl, const int64_t* d_chosen, const int64_t* d_best_n, const float* d_logp,
-                    const int64_t* d_cand, int width, const int32_t* d_len, const int32_t* d_chosen_slot,
-                    const uint8_t* d_finished, int B, int beam, int dl, int V, int K, int pad, int bos, int eos,
-                    int64_t* d_new_cand, float* d_new_logp, int32_t* d_parent, int32_t* d_parent_draft, int32_t* d_mark,
-                    int32_t* h_summary, void* stream);
-
 /* TranslationInferenceBeamSearchSpeculative.generate (src/decoding/speculative_decoding.py:241-869) — the whole loop on the
  * device: generate_trying_all_the_drafts (:428-598) or generate_with_smart_drafts (:600-845), `sample` (:294-400),
  * calculate_n_accepted_in_drafts (:847-869), mask_with_num_logits_according_nucleus (:871-904) and topk_in_each_group
@@ -216,6 +202,12 @@ typedef struct ttx_beam_stats {
   int64_t running_rows;            /* of those, rows of unfinished candidates (the reference's b_sz)        */
   int64_t accepted_tokens;         /* generator.accepted_tokens_num                                         */
   int64_t produced_non_pad_tokens; /* generator.produced_non_pad_tokens                                     */
+  int64_t verified_positions;      /* decoder positions the KV-cached algorithm needs (running candidates + draft tokens) */
+  int64_t executed_positions;      /* rows of the step GEMMs actually computed (unused smart-mode draft slots included) */
+  int64_t kv_prefix_positions;     /* cached prefix positions attended                                      */
+  int64_t running_candidates;      /* sum over iterations of unfinished candidates                          */
+  int64_t src_tokens_padded;       /* encoder positions computed: B x Ls                                    */
+  double  encode_ms, decode_ms;    /* device time (HIP events) of encoder + cross K/V + drafts / of the loop */
   int32_t out_width;               /* W: columns of the result tensor                                       */
   int32_t status;                  /* this batch's own status (the *_many call returns the first failure)   */
 } ttx_beam_stats;

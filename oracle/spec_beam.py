@@ -157,7 +157,8 @@ class BeamSearchSpeculativeOracle:
             for r, (ci, d) in enumerate(zip(rows_cand, rows_draft)):
                 inputs[r, slots[ci]] = d
             self.model_calls_num += 1
-            self.model_input_lines_num += len(rows_cand)
+            if smart:                                                          # only the smart-drafts loop counts them (:741)
+                self.model_input_lines_num += len(rows_cand)
             running = ~(inputs == EOS).any(axis=1)
             logits = torch.zeros((len(rows_cand), dl + 1, V), dtype=torch.float32)
             logits[:, :, PAD] = 35.0                                           # finished rows: ~certain PAD (:466-468)

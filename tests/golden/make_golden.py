@@ -387,7 +387,8 @@ TINY66 = dict(num_encoder_layers=6, num_decoder_layers=6, embedding_dim=64, num_
 
 def section_tiny66():
     src, tgt, c_tok, V = fixture_tokens()
-    torch.manual_seed(654321)
+    torch.manual_seed(1)            # a seed under which the reference's beam-speculative loop terminates on 8 of the 10 rows
+    torch.set_num_threads(2)
     model = build_ref_model(V, TINY66)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     crit = torch.nn.CrossEntropyLoss(reduction="mean")
@@ -410,6 +411,7 @@ def section_tiny66():
         L = int((tgt[i] != PAD).sum())
         ok += int(torch.equal(g[i, 0, :L], tgt[i, :L]))
     print("tiny66: final loss", float(loss), "steps", step, "greedy exact", ok, "/ 10")
+    torch.set_num_threads(8)
     assert ok == 10
     state_to_npz(model, HERE / "tiny66_weights.npz")
     (HERE / "tiny66_config.json").write_text(json.dumps(dict(TINY66, vocab_size=V, share_embeddings=True)))

@@ -26,7 +26,17 @@ def test_nucleus_mask_matches_reference_goldens(native):
         np.testing.assert_array_equal(got, g[f"nuc_out_{tag}"])
 
 
+def _threshold_margin(logits: torch.Tensor, nucleus: float, nbest: int) -> torch.Tensor:
+    """Per distribution: how close the "mass ranked above" of any of the first nbest ranks comes to the nucleus threshold
+    (fp64).  A keep/drop decision can only differ between two correct fp32 evaluations where this is ~1e-6."""
+    srt = torch.sort(logits.double(), descending=True, dim=-1).values
+    above = torch.cumsum(srt.softmax(-1), dim=-1)[..., :nbest]
+    return (above - nucleus).abs().min(dim=-1).values
+
+
 def test_nucleus_mask_random_matches_oracle(native):
+    """Random distributions: identical to the oracle everywhere, except where a rank's mass-above sits within 1e-5 of the
+    threshold in exact arithmetic (the fp32 sums of the two implementations may then fall on different sides)."""
     rng = np.random.default_rng(5)
     for V in (30, 256, 1000):
         x = torch.from_numpy((rng.standard_normal((97, 11, V)) * 4).astype(np.float32))
@@ -36,9 +46,11 @@ def test_nucleus_mask_random_matches_oracle(native):
             want = nucleus_mask(x.clone(), nucleus, nbest, fill)
             got = native.nucleus_mask(x.cuda(), nucleus, nbest, fill).cpu()
             same = (got == want) | (torch.isinf(got) & torch.isinf(want))
-            # a rank whose mass-above sits within fp32 noise of the threshold may fall either way: allow 1e-3 of the rows
-            bad_rows = (~same).any(-1).float().mean().item()
-            assert bad_rows <= 1e-3, (V, nucleus, nbest, bad_rows)
+            bad = ~same.all(-1)
+            if bool(bad.any()):
+                margin = _threshold_margin(x, nucleus, nbest)[bad]
+                print(f"V={V} nucleus={nucleus}: {int(bad.sum())} distribution(s) differ, threshold margin {margin.tolist()}")
+                assert float(margin.max()) < 1e-5, (V, nucleus, nbest)
 
 
 def test_accepted_lengths_matches_oracle(native):
@@ -52,7 +64,11 @@ def test_accepted_lengths_matches_oracle(native):
     alive = probs[:, :-1, :].gather(2, drafts.unsqueeze(-1)).squeeze(-1) != 0
     want = alive.long().cumprod(1).sum(1)
     got = native.accepted_lengths(logits.cuda(), drafts.cuda(), 0.9975, 5).cpu()
-    assert (got == want).float().mean().item() >= 0.995
+    bad = got != want
+    if bool(bad.any()):           # only rows holding a distribution whose threshold decision is within fp32 noise may differ
+        margin = _threshold_margin(logits, 0.9975, 5).min(dim=-1).values[bad]
+        print(f"{int(bad.sum())} draft row(s) differ, threshold margin {margin.tolist()}")
+        assert float(margin.max()) < 1e-5
     assert int(want.max()) > 3 and int(want.min()) == 0
 
 

@@ -82,43 +82,6 @@ def test_beam_matches_reference(tta, tiny):
         assert g.model_calls_num == int(gold[f"b{bsz}_k{beam}_calls"])
 
 
-@pytest.mark.parametrize("smart", [False, True])
-def test_beam_speculative_matches_reference(tta, tiny, smart):
-    """Top-1 hypothesis of every source must be token-identical to the reference.  Lower-ranked hypotheses are
-    ranked by fp32 sums of log-probabilities whose gaps on this overfit tiny model go down to 1.3e-4 (measured with
-    the oracle), i.e. the size of the accumulated fp32 difference between the HIP and the CPU forward (logits agree
-    to ~1.5e-5 per position), so a near-tie may swap: they must still agree for >= 90 % of the hypotheses."""
-    gold = load_npz("gen_spec_beam.npz")
-    src, _, c, V = fixture_tokens()
-    ci, same, total = 0, 0, 0
-    while f"smart{int(smart)}_case{ci}_rows" in gold:
-        key = f"smart{int(smart)}_case{ci}"
-        rows = gold[key + "_rows"].tolist()
-        bsz, nbest, N, D = gold[key + "_params"].tolist()
-        g = tta.TranslationInferenceBeamSearchSpeculative(tiny, 150, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=400)
-        exact = True
-        for bi, i in enumerate(range(0, len(rows), bsz)):
-            sel = src[rows[i:i + bsz]]
-            width = int((sel != PAD).sum(1).max())
-            out = g.generate(sel[:, :width].cuda()).cpu().numpy()
-            ref = gold[f"{key}_batch{bi}"]
-            assert out.shape[:2] == ref.shape[:2]
-            for b in range(out.shape[0]):
-                assert upto_eos(out[b, 0]) == upto_eos(ref[b, 0]), (key, bi, b)
-                for k in range(out.shape[1]):
-                    eq = upto_eos(out[b, k]) == upto_eos(ref[b, k])
-                    same += int(eq)
-                    total += 1
-                    exact &= eq
-        if exact:
-            assert g.model_calls_num == int(gold[key + "_calls"])
-            assert g.accepted_tokens_num == int(gold[key + "_accepted"])
-            assert g.produced_non_pad_tokens == int(gold[key + "_produced"])
-        ci += 1
-    print(f"beam-speculative smart={smart}: {same}/{total} hypotheses token-identical to the reference")
-    assert same >= 0.9 * total
-
-
 def test_full_size_greedy_speculative_matches_oracle(tta, full_pair):
     from oracle.decoding import GreedySpeculativeOracle, GreedyOracle
     native, oracle = full_pair
@@ -150,22 +113,6 @@ def test_full_size_greedy_and_beam_match_oracle(tta, full_pair):
     outb = tta.TranslationInferenceBeamSearch(native, 5, 200, PAD, BOS, EOS).generate(src[:4].cuda()).cpu().numpy()
     for b in range(4):
         assert upto_eos(outb[b, 0]) == upto_eos(expb[b, 0])     # top-1 hypothesis identical
-
-
-def test_full_size_beam_speculative_matches_oracle(tta, full_pair):
-    from oracle.spec_beam import BeamSearchSpeculativeOracle
-    native, oracle = full_pair
-    src, _, c, V = fixture_tokens()
-    rows = [0, 2, 4, 6]
-    sel = src[rows]
-    sel = sel[:, :int((sel != PAD).sum(1).max())]
-    for smart in (False, True):
-        ref = BeamSearchSpeculativeOracle(oracle, 200, 5, 10, 7, V, smart, PAD, BOS, EOS, c, max_steps=300)
-        exp = ref.generate(sel).numpy()
-        g = tta.TranslationInferenceBeamSearchSpeculative(native, 200, 5, 10, 7, V, smart, PAD, BOS, EOS, c, max_steps=300)
-        out = g.generate(sel.cuda()).cpu().numpy()
-        for b in range(len(rows)):
-            assert upto_eos(out[b, 0]) == upto_eos(exp[b, 0]), (smart, b)
 
 
 def test_kv_cached_step_logits_match_full_prefix_oracle(tta, full_pair):

@@ -51,3 +51,33 @@ def test_generate_matches_reference(model, smart):
         assert g.produced_non_pad_tokens == int(gold[key + "_produced"]), key
         ci += 1
     assert ci >= 5
+
+
+@pytest.mark.parametrize("smart", [False, True])
+def test_six_plus_six_layers_c4_shape_matches_reference(smart):
+    """6+6 layers at config C4's generator settings (bs 8, n_best 10, n_drafts 2, draft_len 10, max_len 200) and two
+    neighbours: the oracle against the reference's outputs in tests/golden/gen_spec_beam66.npz."""
+    import json
+    from util_models import GOLDEN
+    st = load_npz("tiny66_weights.npz")
+    cfg = json.loads((GOLDEN / "tiny66_config.json").read_text())
+    m = OracleTransformer(config_from_state(st, cfg["num_heads"]), st)
+    assert m.cfg["num_decoder_layers"] == 6 if isinstance(getattr(m, "cfg", None), dict) else True
+    gold = load_npz("gen_spec_beam66.npz")
+    src, _, c, V = fixture_tokens()
+    ci = 0
+    while f"smart{int(smart)}_case{ci}_rows" in gold:
+        key = f"smart{int(smart)}_case{ci}"
+        rows = gold[key + "_rows"].tolist()
+        bsz, nbest, N, D = gold[key + "_params"].tolist()
+        g = BeamSearchSpeculativeOracle(m, 200, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=400)
+        for bi, i in enumerate(range(0, len(rows), bsz)):
+            sel = src[rows[i:i + bsz]]
+            width = int((sel != PAD).sum(1).max())
+            np.testing.assert_array_equal(g.generate(sel[:, :width]).numpy(), gold[f"{key}_batch{bi}"], err_msg=f"{key} batch {bi}")
+        assert g.model_calls_num == int(gold[key + "_calls"]), key
+        assert g.accepted_tokens_num == int(gold[key + "_accepted"]), key
+        assert g.produced_non_pad_tokens == int(gold[key + "_produced"]), key
+        assert g.model_input_lines_num == int(gold[key + "_lines"]), key
+        ci += 1
+    assert ci == 3

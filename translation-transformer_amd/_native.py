@@ -55,8 +55,10 @@ class BeamParams(C.Structure):
 
 class BeamStats(C.Structure):
     _fields_ = [("model_calls", C.c_int64), ("input_lines", C.c_int64), ("running_rows", C.c_int64),
-                ("accepted_tokens", C.c_int64), ("produced_non_pad_tokens", C.c_int64), ("out_width", C.c_int32),
-                ("status", C.c_int32)]
+                ("accepted_tokens", C.c_int64), ("produced_non_pad_tokens", C.c_int64), ("verified_positions", C.c_int64),
+                ("executed_positions", C.c_int64), ("kv_prefix_positions", C.c_int64), ("running_candidates", C.c_int64),
+                ("src_tokens_padded", C.c_int64), ("encode_ms", C.c_double), ("decode_ms", C.c_double),
+                ("out_width", C.c_int32), ("status", C.c_int32)]
 
 
 class GenStats(C.Structure):
@@ -99,8 +101,6 @@ SYMBOLS = {
     "ttx_nucleus_mask": (C.c_int, [_VP, _VP, _I, _I, C.c_float, _I, C.c_float, _VP, _VP]),
     "ttx_accepted_lengths": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _I, _VP, _VP]),
     "ttx_ragged_topk": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
-    "ttx_beam_expand": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP,
-                                  _VP, _VP, C.POINTER(C.c_int32), _VP]),
     "ttx_tree_begin": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "ttx_tree_step": (C.c_int, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "ttx_tokenizer_create": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), _I, C.POINTER(_VP)]),

@@ -1841,51 +1841,6 @@ extern "C" int ttx_ragged_topk(ttx_session* s, const float* d_score, const int32
   return TTX_OK;
 }
 
-// Candidate expansion of one beam-speculative iteration (`sample` + per-source top-n_best + row assembly:
-// speculative_decoding.py:294-400, :573-598).  h_summary (HOST, int32[5]): new candidates holding EOS, minimum PAD count
-// over the new rows, sum and count of the accepted-token marks >= 0, error flag (a source with fewer than K leaves).
-extern "C" int ttx_beam_expand(ttx_session* s, const float* d_cl, const int64_t* d_chosen, const int64_t* d_best_n,
-                               const float* d_logp, const int64_t* d_cand, int width, const int32_t* d_len,
-                               const int32_t* d_chosen_slot, const uint8_t* d_finished, int B, int beam, int dl, int V, int K,
-                               int pad, int bos, int eos, int64_t* d_new_cand, float* d_new_logp, int32_t* d_parent,
-                               int32_t* d_parent_draft, int32_t* d_mark, int32_t* h_summary, void* stream) {
-  if (!s || !d_cl || !d_chosen || !d_best_n || !d_logp || !d_cand || !d_len || !d_chosen_slot || !d_finished || !d_new_cand ||
-      !d_new_logp || !d_parent || !d_parent_draft || !d_mark || !h_summary)
-    return fail(TTX_ERR_INVALID, "null argument to ttx_beam_expand");
-  if (B <= 0 || beam <= 0 || dl <= 0 || V <= 0 || V > 64 * NUC_VPL || K < 1 || K > NUC_MAX_KEEP || width < dl + 2)
-    return fail(TTX_ERR_INVALID, "ttx_beam_expand: shape outside the kernels' limits");
-  const int dl1 = dl + 1, n_cand = B * beam;
-  const size_t L = (size_t)beam * dl1 * K;
-  if (beam * dl1 > 1023 || 2 * L * 4 > 150 * 1024) return fail(TTX_ERR_INVALID, "ttx_beam_expand: too many leaves per source for the LDS image");
-  HIP_TRY(hipSetDevice(s->m->device));
-  hipStream_t st = (hipStream_t)stream;
-  TTX_TRY(ensure(s->leaf_score, (size_t)n_cand * dl1 * K * 4, st));
-  TTX_TRY(ensure(s->leaf_tok, (size_t)n_cand * dl1 * K * 4, st));
-  TTX_TRY(ensure(s->leaf_cnt, (size_t)n_cand * dl1 * 4, st));
-  TTX_TRY(ensure(s->beam_summary, 8 * 4, st));
-  const int init[5] = {0, 0x7fffffff, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(s->beam_summary.p, init, sizeof(init), hipMemcpyHostToDevice, st));
-  BeamLeavesArgs la{d_cl, d_chosen, d_best_n, d_logp, n_cand, dl, V, K, bos, s->leaf_score.as<float>(), s->leaf_tok.as<int>(),
-                    s->leaf_cnt.as<int>()};
-  hipLaunchKernelGGL(k_beam_leaves, dim3(n_cand), dim3(256), (size_t)2 * dl1 * 4, st, la);
-  HIP_TRY(hipGetLastError());
-  BeamSelectArgs<int64_t> sa{s->leaf_score.as<float>(), s->leaf_tok.as<int>(), s->leaf_cnt.as<int>(), d_cand, width, width, width,
-                             d_len, d_chosen, d_chosen_slot, d_finished, B, beam, dl, K, pad, eos, d_new_cand, d_new_logp, d_parent,
-                             d_parent_draft, d_mark, s->beam_summary.as<int>(), nullptr, nullptr};
-  const size_t lds = 2 * L * 4;
-  static bool attr = false;
-  if (lds > 64 * 1024 && !attr) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_beam_select<int64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr = true;
-  }
-  hipLaunchKernelGGL(k_beam_select<int64_t>, dim3(B), dim3(256), lds, st, sa);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h_summary, s->beam_summary.p, 5 * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  if (h_summary[4]) return fail(TTX_ERR_REFERENCE, "a source has fewer candidate leaves than n_best (the reference asserts here, speculative_decoding.py:195)");
-  return TTX_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Beam-search speculative decoding, whole loop native (speculative_decoding.py:428-598 all drafts, :600-845 smart drafts).
 // Device kernels of one iteration: see "Native beam-speculative loop" in ttx_kernels.hip.h.  The host keeps the loop
@@ -1980,6 +1935,8 @@ static int beam_start(BeamJob& j, ttx_session* s, hipStream_t st, const int64_t*
   }
   std::memset(s->beam_host, 0, sizeof(BeamHost));
 
+  s->ev_used = 0;
+  HIP_TRY(hipEventRecord(s->ev_a, st));
   // encoder + cross K/V once per source (:439 / :626); drafts (:430) or the draft library (:603-615)
   TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
   TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));
@@ -1995,6 +1952,7 @@ static int beam_start(BeamJob& j, ttx_session* s, hipStream_t st, const int64_t*
                      s->bs_fin_next.as<uint8_t>(), s->bs_logp_next.as<float>(), s->bs_parent.as<int>(), s->bs_parent_draft.as<int>(),
                      j.max_cand, B, p->bos_token, p->pad_token, s->bs_cnt.as<BeamCounters>());
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev_b, st));
   // candidate c of an iteration belongs to source c / beam: the tree kernels read the map from t_src_of, filled per iteration
   j.n_cand = B; j.beam = 1; j.dl = j.D0; j.width = 1; j.empty_cols = 0; j.after_last = 1;
   j.room = p->max_len - j.after_last - 1;
@@ -2140,6 +2098,7 @@ static int beam_finish_enqueue(BeamJob& j) {
   if (j.width > j.p.max_len) return fail(TTX_ERR_HIP, "beam-speculative loop: result wider than max_len (internal error)");
   HIP_TRY(hipMemcpy2DAsync(j.d_out, (size_t)j.p.max_len * 8, s->bs_cand_next.p, (size_t)j.gen_ld * 8, (size_t)j.width * 8,
                            (size_t)j.B * j.K, hipMemcpyDeviceToDevice, j.st));
+  HIP_TRY(hipEventRecord(s->ev_c, j.st));
   HIP_TRY(hipMemcpyAsync(s->host_state, s->bs_cnt.p, sizeof(BeamCounters), hipMemcpyDeviceToHost, j.st));
   HIP_TRY(hipEventRecord(s->ev_done, j.st));
   j.phase = 2;
@@ -2151,6 +2110,15 @@ static void beam_collect(BeamJob& j) {
   j.acc.model_calls = cn->model_calls;
   j.acc.input_lines = cn->input_lines;
   j.acc.running_rows = cn->running_rows;
+  j.acc.verified_positions = cn->verified_positions;
+  j.acc.executed_positions = cn->executed_positions;
+  j.acc.kv_prefix_positions = cn->kv_prefix_positions;
+  j.acc.running_candidates = cn->running_cands;
+  j.acc.src_tokens_padded = (int64_t)j.B * j.Ls;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, j.s->ev_a, j.s->ev_b) == hipSuccess) j.acc.encode_ms = ms;
+  if (hipEventElapsedTime(&ms, j.s->ev_b, j.s->ev_c) == hipSuccess) j.acc.decode_ms = ms;
+  collect_gemm_profile(j.s, j.st);
   j.acc.out_width = j.width;
   j.acc.status = j.rc;
   if (j.stats) *j.stats = j.acc;

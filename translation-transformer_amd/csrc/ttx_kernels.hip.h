@@ -2303,15 +2303,6 @@ __global__ __launch_bounds__(256) void k_ragged_topk(RaggedTopkArgs a) {
 //     which is the order torch.nonzero enumerates them in.
 //   k_beam_select: one workgroup per source.  The n_best best leaves of the source's candidates, best first (ties: earlier
 //     in enumeration order), and the rows of the new candidates: root tokens, the kept draft tokens, the leaf token.
-struct BeamLeavesArgs {
-  const float* cl;            // [n_cand, dl+1, V] logits along each candidate's chosen draft
-  const int64_t* chosen;      // [n_cand, dl]
-  const int64_t* best_n;      // [n_cand] accepted draft tokens
-  const float* logp;          // [n_cand]
-  int n_cand, dl, V, K, bos;
-  float* leaf_score; int* leaf_tok; int* leaf_cnt;   // [n_cand, dl+1, K], [n_cand, dl+1, K], [n_cand, dl+1]
-};
-
 // Core of the leaf enumeration for one candidate `c` (the whole workgroup): `rowp(p)` = logits row of position p along
 // the candidate's chosen draft, `chosen(p)` = its p-th draft token.
 template <class RowPtr, class Chosen>
@@ -2372,16 +2363,6 @@ __device__ __forceinline__ void beam_leaves_core(int c, int nacc, float root, in
       *ls = root + stepsum;
     }
   }
-}
-
-__global__ __launch_bounds__(256) void k_beam_leaves(BeamLeavesArgs a) {
-  extern __shared__ float lp_kept[];          // [dl+1] log-softmax of the kept (chosen) token at every position, then [dl+1] sums
-  const int c = blockIdx.x;
-  const int dl1 = a.dl + 1;
-  beam_leaves_core(c, (int)a.best_n[c], a.logp[c], a.dl, a.V, a.K, a.bos,
-                   [&](int p) { return a.cl + ((size_t)c * dl1 + p) * a.V; },
-                   [&](int p) { return (int)a.chosen[(size_t)c * a.dl + p]; },
-                   a.leaf_score, a.leaf_tok, a.leaf_cnt, lp_kept);
 }
 
 template <typename TokT>
@@ -2607,6 +2588,10 @@ struct BeamHost { int steps_done; int summary[5]; };     // pinned, device-mappe
 
 struct BeamCounters {          // device-resident sums of one generate call
   long long model_calls, input_lines, running_rows;
+  long long verified_positions;   // decoder positions the KV-cached algorithm needs: running candidates + their drafts' tokens
+  long long executed_positions;   // rows of the step GEMMs (unused draft slots of smart mode included)
+  long long kv_prefix_positions;  // cached prefix positions attended (sum over running candidates of len - 1)
+  long long running_cands;        // sum over iterations of running candidates
   int max_group;               // smart drafts: largest number of drafts any candidate tries in the current iteration
   int pad_;
 };
@@ -2685,9 +2670,9 @@ struct BeamListArgs {
 // work from, the iteration's counters, and the reset of the selection summary.
 __global__ __launch_bounds__(256) void k_bs_list(BeamListArgs a) {
   __shared__ int s_scan[256];
-  __shared__ int s_lines, s_run, s_maxg;
+  __shared__ int s_lines, s_run, s_maxg, s_prefix;
   const int t = threadIdx.x;
-  if (t == 0) { s_lines = 0; s_run = 0; s_maxg = 0; }
+  if (t == 0) { s_lines = 0; s_run = 0; s_maxg = 0; s_prefix = 0; }
   __syncthreads();
   int before = 0;
   for (int base = 0; base < a.n_cand; base += 256) {
@@ -2698,7 +2683,7 @@ __global__ __launch_bounds__(256) void k_bs_list(BeamListArgs a) {
       const int pc = a.per_cand[c];
       a.slot_of[c] = act ? before + incl - 1 : -1;
       a.prev_len[c] = a.len[c];
-      if (act) { a.act_idx[before + incl - 1] = c; atomicAdd(&s_run, pc); }
+      if (act) { a.act_idx[before + incl - 1] = c; atomicAdd(&s_run, pc); atomicAdd(&s_prefix, a.len[c] - 1); }
       atomicAdd(&s_lines, pc);
       atomicMax(&s_maxg, pc);
     }
@@ -2714,6 +2699,10 @@ __global__ __launch_bounds__(256) void k_bs_list(BeamListArgs a) {
     a.cnt->model_calls += 1;
     a.cnt->input_lines += s_lines;
     a.cnt->running_rows += s_run;
+    a.cnt->verified_positions += before + (long long)s_run * a.dl;
+    a.cnt->executed_positions += (long long)before * step_rps(a.N, a.dl);
+    a.cnt->kv_prefix_positions += s_prefix;
+    a.cnt->running_cands += before;
     a.cnt->max_group = s_maxg;
     a.summary[0] = 0; a.summary[1] = 0x7fffffff; a.summary[2] = 0; a.summary[3] = 0; a.summary[4] = 0;
   }
@@ -2826,7 +2815,10 @@ __global__ void k_bs_init(int64_t* cand_next, int ld, int* len_next, uint8_t* fi
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   for (int i = tid; i < max_cand * ld; i += nth) cand_next[i] = (i % ld == 0 && i / ld < B) ? bos : pad;
   for (int i = tid; i < max_cand; i += nth) { len_next[i] = 1; fin_next[i] = 0; logp_next[i] = 0.f; parent[i] = -1; parent_draft[i] = 0; }
-  if (tid == 0) { cnt->model_calls = 0; cnt->input_lines = 0; cnt->running_rows = 0; cnt->max_group = 0; cnt->pad_ = 0; }
+  if (tid == 0) {
+    cnt->model_calls = 0; cnt->input_lines = 0; cnt->running_rows = 0; cnt->verified_positions = 0; cnt->executed_positions = 0;
+    cnt->kv_prefix_positions = 0; cnt->running_cands = 0; cnt->max_group = 0; cnt->pad_ = 0;
+  }
 }
 
 }  // namespace ttx

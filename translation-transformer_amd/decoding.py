@@ -264,33 +264,6 @@ class TranslationInferenceGreedySpeculative:
         return outs
 
 
-# =====================================================================================================
-# Beam paths.  The model forward (encoder, full-prefix decoder, classifier) and the draft maker run in
-# libttx_hip.so through the model protocol; candidate bookkeeping is tensor algebra on the device with
-# torch as the array library (SURVEY.md §2.3 K11-K14 name the fused kernels that replace it next).
-# The classes accept any object with the B5 protocol so the host logic can be unit-tested on CPU against
-# the reference's golden outputs; the public constructors insist on a NativeTransformer.
-# =====================================================================================================
-def _decode(model, tgt, memory, mask, rows):
-    """decode_tgt for decoder rows that share `memory` rows: the HIP path takes the row map, a generic
-    B5 model gets the gathered ("inflated") memory the reference builds."""
-    if isinstance(model, NativeTransformer):
-        return model.decode_tgt(tgt, memory, memory_pad_mask=mask, memory_row=rows.to(torch.int32))
-    return model.decode_tgt(tgt, memory[rows], memory_pad_mask=mask[rows])
-
-
-def _use_kv_cache(model) -> bool:
-    """Beam paths on the HIP model decode through the per-candidate KV cache (ttx_tree_*) unless TTX_BEAM_KV_CACHE=0."""
-    return isinstance(model, NativeTransformer) and os.environ.get("TTX_BEAM_KV_CACHE", "1") != "0"
-
-
-def _drafts(model, src, draft_len, n_drafts, lo, hi, eos, pad, repl):
-    if isinstance(model, NativeTransformer):
-        return model.make_drafts(src, draft_len, n_drafts, lo, hi, eos, pad, repl)
-    from . import _hostref  # CPU-only unit tests of the host logic
-    return _hostref.make_drafts(src, draft_len, n_drafts, lo, hi, eos, pad, repl)
-
-
 class TranslationInferenceGreedy:
     """Drop-in for src/decoding/standard_decoding.py:4-55; the loop runs in ttx_greedy_generate (KV cache)."""
 
@@ -319,13 +292,15 @@ class TranslationInferenceGreedy:
         return out
 
 
-class _BeamSearchHost:
-    """Standard beam search (src/decoding/standard_decoding.py:58-174)."""
+class TranslationInferenceBeamSearch:
+    """Standard beam search (src/decoding/standard_decoding.py:58-174): the decoder runs on a per-hypothesis KV cache
+    (ttx_tree_begin / ttx_tree_step: encoder and cross K/V once per source); the beam update of a step is array algebra
+    on the device."""
 
     def __init__(self, model, beam_size: int, max_len: int, pad_token: int, bos_token: int, eos_token: int):
         assert max_len > 1
         assert beam_size > 0
-        self.model = model
+        self.model = _need_native(model)
         self.beam_size, self.max_len = beam_size, max_len
         self.pad_token, self.bos_token, self.eos_token = pad_token, bos_token, eos_token
         self.model_calls_num = 0
@@ -337,17 +312,15 @@ class _BeamSearchHost:
 
     def generate(self, src: torch.Tensor) -> torch.Tensor:
         m, K = self.model, self.beam_size
-        dev = getattr(m, "device", src.device)
-        src = src.to(dev)
+        dev = m.device
+        src = src.to(dev, torch.int64)
+        m.check_tokens(src)
         B = src.size(0)
         pad_col = m.src_pad_token_i                                   # standard_decoding.py:135
-        tree = TreeDecoder(m, src, B * K, self.max_len, 1, 0) if _use_kv_cache(m) else None
+        tree = TreeDecoder(m, src, B * K, self.max_len, 1, 0)
         y0 = torch.full((B, 1), self.bos_token, dtype=src.dtype, device=dev)
-        if tree is not None:
-            ones = torch.ones(B, dtype=torch.int32, device=dev)
-            first = tree.step(y0, ones, -ones, 0 * ones, torch.arange(B, device=dev), ones.bool(), None, 1, 0)[:, 0]
-        else:
-            first = m(src, y0)                                        # :102
+        ones = torch.ones(B, dtype=torch.int32, device=dev)
+        first = tree.step(y0, ones, -ones, 0 * ones, torch.arange(B, device=dev), ones.bool(), None, 1, 0)[:, 0]   # :102
         self.b_sz += B
         self.model_calls_num += 1
         self.given_tokens += int((src != pad_col).sum())
@@ -357,21 +330,15 @@ class _BeamSearchHost:
         # the reference re-encodes the source once per beam (:120-124); the rows are identical, so the HIP path
         # encodes once and lets the K beams of a source share that memory row
         owner = torch.arange(B, device=dev).repeat_interleave(K)
-        if tree is None:
-            mask = src == pad_col
-            memory = m.encode_src(src, mask)
         prev_parent = owner.clone()                                   # row (b,k) extends the <BOS> row of source b
         for _ in range(self.max_len - 2):
             alive = ~((y == self.eos_token).any(dim=1))
             self.b_sz += int(alive.sum())
             step = torch.zeros((B * K, V), dtype=torch.float32, device=dev)
             step[:, pad_col] = 35.0
-            if tree is not None:
-                length = torch.full((B * K,), y.size(1), dtype=torch.int32, device=dev)
-                out = tree.step(y, length, prev_parent, torch.zeros_like(length), owner, alive, None, 1, 0)[:, 0, 0]
-                step[alive] = out[alive]
-            else:
-                step[alive] = _decode(m, y[alive], memory, mask, owner[alive])[:, -1, :]
+            length = torch.full((B * K,), y.size(1), dtype=torch.int32, device=dev)
+            out = tree.step(y, length, prev_parent, torch.zeros_like(length), owner, alive, None, 1, 0)[:, 0, 0]
+            step[alive] = out[alive]
             self.model_calls_num += 1
             total = (score.unsqueeze(-1) + torch.log(torch.softmax(step, dim=-1)).reshape(B, K, V)).reshape(B, K * V)
             score, flat = total.topk(K, dim=-1, sorted=True)
@@ -381,242 +348,6 @@ class _BeamSearchHost:
             if bool((y == self.eos_token).any(dim=1).all()):
                 break
         return y.reshape(B, K, -1)
-
-
-def _nucleus(logits: torch.Tensor, nucleus: float, max_kept: int, fill: float) -> torch.Tensor:
-    """speculative_decoding.py:871-904: best-first, keep while the mass ranked above is < nucleus, <= max_kept."""
-    shape = logits.shape
-    flat = logits.reshape(-1, shape[-1])
-    srt, order = torch.sort(flat, descending=True)
-    above = torch.cumsum(srt.softmax(-1), dim=-1).roll(1, dims=-1)
-    above[:, 0] = nucleus - 1
-    keep = above < nucleus
-    keep[:, max_kept:] = False
-    srt = srt.masked_fill(~keep, fill)
-    return torch.gather(srt, 1, order.argsort(1)).reshape(shape)
-
-
-def _ragged_topk(score: torch.Tensor, counts: torch.Tensor, k: int, pad: float):
-    """Top-k of every consecutive group of `score` (group g has counts[g] entries): (values [G,k], flat idx [G*k])."""
-    G = counts.numel()
-    starts = torch.cumsum(counts, 0) - counts
-    width = int(counts.max())
-    assert int(counts.min()) >= k
-    col = torch.arange(score.numel(), device=score.device) - starts.repeat_interleave(counts)
-    table = torch.full((G, width), pad, dtype=score.dtype, device=score.device)
-    table[torch.arange(G, device=score.device).repeat_interleave(counts), col] = score
-    top, idx = table.topk(k, dim=-1, sorted=True)
-    return top, (idx + starts.unsqueeze(1)).reshape(-1)
-
-
-class _BeamSearchSpeculativeHost:
-    """Beam-search speculative decoding, both draft modes (src/decoding/speculative_decoding.py:241-869)."""
-
-    def __init__(self, model, max_len: int, n_best: int, draft_len: int, n_drafts: int, vocab_size: int,
-                 smart_drafts_mode: bool, pad_token: int, bos_token: int, eos_token: int, C_token: int,
-                 max_steps: int | None = None) -> None:
-        self.model = model
-        self.max_len, self.vocab_size = max_len, vocab_size
-        self.smart_drafts_mode = smart_drafts_mode
-        self.pad_token_idx, self.bos_token_idx, self.eos_token_idx, self.C_token_idx = pad_token, bos_token, eos_token, C_token
-        self.n_best = n_best
-        self.accepted_tokens_num = 0
-        self.model_calls_num = 0
-        self.model_input_lines_num = 0
-        self.max_drafts_num = n_drafts
-        self.n_drafts = 0
-        self.requested_drafts_num = n_drafts
-        self.produced_non_pad_tokens = 0
-        self.max_draft_len, self.min_draft_len = 200, 5
-        clamped = min(max(self.min_draft_len, draft_len), self.max_draft_len)
-        if clamped != draft_len:
-            print(f"The draft length should be in range [{self.min_draft_len}: {self.max_draft_len}], so it was changed to {clamped}")
-        self.draft_len = clamped
-        self.b_sz = 0
-        # Safety valve absent from the reference, whose loop never ends when a candidate keeps emitting PAD
-        # before any EOS; None = reference behaviour.
-        self.max_steps = max_steps
-
-    def __str__(self):
-        return (f"SpeculativeSampling decoding (n_best={self.n_best}, max_len={self.max_len}, "
-                f"max_num_of_drafts={self.max_drafts_num}, draft_len={self.draft_len})")
-
-    def generate(self, src: torch.Tensor) -> torch.Tensor:
-        m, K, V = self.model, self.n_best, self.vocab_size
-        PAD, BOS, EOS = self.pad_token_idx, self.bos_token_idx, self.eos_token_idx
-        dev = getattr(m, "device", src.device)
-        src = src.to(dev)
-        B = src.size(0)
-        smart = self.smart_drafts_mode
-        mask = src == m.src_pad_token_i
-        memory = m.encode_src(src, mask)
-        if smart:
-            lib = _drafts(m, src, self.draft_len + 1, src.shape[1] - 5, self.min_draft_len, self.max_draft_len, EOS, PAD,
-                          self.C_token_idx)                                   # [B, n_lib, D+1], BOS windows included
-            dl = lib.size(2) - 1
-        else:
-            drafts_all = _drafts(m, src[:, 1:], self.draft_len, self.requested_drafts_num, self.min_draft_len,
-                                 self.max_draft_len, EOS, PAD, self.C_token_idx)  # [B, N, D]
-            dl = drafts_all.size(2)
-            self.n_drafts += B * drafts_all.size(1)
-
-        cand = torch.full((B, 1), BOS, dtype=torch.int64, device=dev)
-        logp = torch.zeros(B, dtype=torch.float32, device=dev)
-        n_slots = self.requested_drafts_num if smart else drafts_all.size(1)
-        kvdec = TreeDecoder(m, src, B * K, self.max_len, n_slots, dl) if _use_kv_cache(m) else None
-        prev_parent = torch.full((B,), -1, dtype=torch.int64, device=dev)
-        prev_pdraft = torch.zeros(B, dtype=torch.int64, device=dev)
-        empty_cols, after_last = 0, 1
-        room = self.max_len - after_last - 1
-        steps = 0
-        while room >= 1 and after_last <= self.max_len:
-            if self.max_steps is not None and steps >= self.max_steps:
-                raise RuntimeError("beam-speculative loop exceeded max_steps (non-terminating input)")
-            steps += 1
-            dl = min(room, dl)
-            grow = dl + 1 - empty_cols
-            if grow > 0:
-                cand = torch.cat([cand, torch.full((cand.size(0), grow), PAD, dtype=torch.int64, device=dev)], dim=1)
-            n_cand, width = cand.shape
-            beam = 1 if n_cand == B else K
-            owner = torch.arange(n_cand, device=dev) // beam                   # source row of every candidate
-            pads = cand == PAD
-            slot = pads & (pads.cumsum(-1) <= dl)                              # first dl PAD columns of each row
-
-            # (candidate, draft) rows of this verify pass
-            if smart:
-                last = cand.gather(1, ((~pads).sum(-1) - 1).unsqueeze(1))      # [n_cand,1]
-                match = lib[owner, :, 0] == last                               # [n_cand, n_lib]
-                match[match.sum(-1) == 0, 0] = True
-                match &= match.cumsum(-1) <= self.requested_drafts_num
-                row_c, row_j = torch.nonzero(match, as_tuple=True)
-                row_d = lib[owner[row_c], row_j, 1:dl + 1]
-                per_cand = match.sum(-1)
-            else:
-                Nn = drafts_all.size(1)
-                row_c = torch.arange(n_cand, device=dev).repeat_interleave(Nn)
-                row_d = drafts_all[owner, :, :dl].reshape(n_cand * Nn, dl)
-                per_cand = None
-            inputs = cand[row_c]
-            inputs[slot[row_c]] = row_d.reshape(-1)
-            self.model_calls_num += 1
-            self.model_input_lines_num += int(row_c.numel())
-            running = ~((inputs == EOS).any(dim=1))
-            logits = torch.zeros((row_c.numel(), dl + 1, V), dtype=torch.float32, device=dev)
-            logits[:, :, PAD] = 35.0
-            self.b_sz += int(running.sum())
-            if kvdec is not None:
-                # the cache assumes left-aligned rows; a running row with a PAD before its last real token (the model
-                # sampled PAD before EOS) makes the reference overwrite that PAD with a draft: leave the cached path
-                irregular = (pads.cummax(dim=-1).values & ~pads).any(dim=-1) & ~((cand == EOS).any(dim=-1))
-                if bool(irregular.any()):
-                    kvdec = None
-            if smart:
-                start = per_cand.cumsum(0) - per_cand
-                row_slot = torch.arange(row_c.numel(), device=dev) - start[row_c]
-            else:
-                row_slot = torch.arange(row_c.numel(), device=dev) % n_slots
-            if kvdec is not None:
-                if smart:                                                       # unused slots repeat the first draft
-                    slots = row_d[start].unsqueeze(1).repeat(1, n_slots, 1)
-                    slots[row_c, row_slot] = row_d
-                else:
-                    slots = row_d.reshape(n_cand, n_slots, dl)
-                out = kvdec.step(cand, (~pads).sum(-1), prev_parent, prev_pdraft, owner, ~((cand == EOS).any(dim=-1)), slots,
-                                n_slots, dl)
-                logits[running] = out[row_c[running], row_slot[running]]
-            elif bool(running.any()):
-                out = _decode(m, inputs[running], memory, mask, owner[row_c[running]])
-                look = slot[row_c[running]]
-                look = look | look.roll(-1, dims=1)
-                logits[running] = out[look].reshape(-1, dl + 1, V)
-
-            native = isinstance(m, NativeTransformer) and os.environ.get("TTX_BEAM_NATIVE_BOOKKEEPING", "1") != "0"
-            if native:                                                          # K11 fused with the acceptance count
-                n_ok = m.accepted_lengths(logits, row_d, 0.9975, K)
-            else:
-                probs = _nucleus(logits, 0.9975, K, float("-inf")).softmax(-1)
-                alive = probs[:, :-1, :].gather(2, row_d.unsqueeze(-1)).squeeze(-1) != 0.0
-                n_ok = alive.long().cumprod(dim=1).sum(dim=1)
-            if smart:
-                if native:
-                    best_n, best_row = m.ragged_topk(n_ok.float(), per_cand, 1)
-                    best_n = best_n.long()
-                else:
-                    best_n, best_row = _ragged_topk(n_ok, per_cand, 1, -1)
-                best_n = best_n.reshape(-1)
-            else:
-                best_n, which = n_ok.reshape(n_cand, Nn).topk(1, dim=-1)
-                best_n = best_n.reshape(-1)
-                best_row = torch.arange(n_cand, device=dev) * Nn + which.reshape(-1)
-            chosen = row_d[best_row].clone()
-            cl = logits[best_row]
-
-            if native and kvdec is not None and beam * (dl + 1) <= 1023 and 8 * beam * (dl + 1) * K <= 150 * 1024 \
-                    and os.environ.get("TTX_BEAM_NATIVE_EXPAND", "1") != "0":
-                # K12 + K13 + K14 in two kernels: leaf enumeration/scoring per candidate, selection + row assembly per source
-                cand, logp, prev_parent, prev_pdraft, mark, summ = m.beam_expand(
-                    cl, chosen, best_n, logp, cand, (~pads).sum(-1), row_slot[best_row], (cand == EOS).any(dim=-1), B, beam, K,
-                    PAD, BOS, EOS)
-                self.accepted_tokens_num += summ[2]
-                self.produced_non_pad_tokens += summ[2] + summ[3]
-                if summ[0] == B * K:
-                    break
-                empty_cols = summ[1]
-                after_last = width - empty_cols
-                room = self.max_len - after_last - 1
-                continue
-
-            pos = torch.arange(dl + 1, device=dev)
-            topn = m.nucleus_mask(cl, 20.0, K, 0.0) if native else _nucleus(cl, 20.0, K, 0.0)
-            tree = topn * (pos.unsqueeze(0) <= best_n.unsqueeze(1)).unsqueeze(-1)
-            short = torch.nonzero(best_n != dl).reshape(-1)
-            chosen[short, best_n[short]] = BOS
-            tree[:, :-1, :].scatter_(2, chosen.unsqueeze(-1), 0.0)
-            lc, lpz, lt = torch.nonzero(tree, as_tuple=True)
-            per_src = torch.bincount(lc // beam, minlength=B)
-
-            seqs = torch.cat([chosen[lc], torch.zeros((lc.numel(), 1), dtype=torch.int64, device=dev)], dim=1)
-            seqs.scatter_(1, lpz.unsqueeze(1), lt.unsqueeze(1))
-            after = pos.unsqueeze(0) > lpz.unsqueeze(1)
-            lp = cl.softmax(-1).log()
-            step_lp = lp[lc.unsqueeze(1), pos.unsqueeze(0), seqs].masked_fill(after, 0.0)
-            run = step_lp[:, 0].clone()
-            for j in range(1, dl + 1):                                          # sequential fp32 sum, column by column
-                run = run + step_lp[:, j]
-            score = logp[lc] + run
-            roots = cand[lc]
-            place = slot[lc]
-            place = place | place.roll(1, dims=1)
-            roots[place] = seqs.masked_fill(after, PAD).reshape(-1)
-            mark = lpz.clone()
-            mark[(cand[lc] == EOS).any(dim=1)] = -1
-
-            if native:
-                assert int(per_src.min()) >= K
-                top_s, top_i = m.ragged_topk(score, per_src, K)
-            else:
-                top_s, top_i = _ragged_topk(score, per_src, K, float("-inf"))
-            prev_parent = lc[top_i]                                             # candidate of this step each survivor extends
-            prev_pdraft = row_slot[best_row][prev_parent]                       # ... and the draft slot it kept tokens from
-            cand = roots[top_i]
-            mark = mark[top_i]
-            mark = mark[mark >= 0]
-            acc = int(mark.sum())
-            self.accepted_tokens_num += acc
-            self.produced_non_pad_tokens += acc + int(mark.numel())
-            if bool((cand == EOS).any(dim=1).all()):
-                break
-            logp = top_s.reshape(-1)
-            empty_cols = int((cand == PAD).sum(-1).min())
-            after_last = width - empty_cols
-            room = self.max_len - after_last - 1
-        return cand.reshape(B, K, -1)
-
-
-class TranslationInferenceBeamSearch(_BeamSearchHost):
-    def __init__(self, model, *a, **k):
-        super().__init__(_need_native(model), *a, **k)
 
 
 class TranslationInferenceBeamSearchSpeculative:
@@ -648,6 +379,9 @@ class TranslationInferenceBeamSearchSpeculative:
         # Safety valve absent from the reference, whose loop never ends when a candidate keeps emitting PAD before any
         # EOS; None = reference behaviour.
         self.max_steps = max_steps
+        # work the device executed, for bench.py's roofline
+        self.stats_total = {"verified_positions": 0, "executed_positions": 0, "kv_prefix_positions": 0, "running_candidates": 0,
+                            "src_tokens_padded": 0, "src_positions": 0, "encode_ms": 0.0, "decode_ms": 0.0, "batches": 0}
         if vocab_size != self.model.tgt_vocab_size:
             raise ValueError("vocab_size differs from the model's target vocabulary")
 
@@ -660,9 +394,16 @@ class TranslationInferenceBeamSearchSpeculative:
                             self.pad_token_idx, self.bos_token_idx, self.eos_token_idx, self.C_token_idx, int(self.max_steps or 0))
 
     def _account(self, st: N.BeamStats, B: int) -> None:
+        t = self.stats_total
+        for k in ("verified_positions", "executed_positions", "kv_prefix_positions", "running_candidates", "src_tokens_padded",
+                  "encode_ms", "decode_ms"):
+            t[k] += getattr(st, k)
+        t["src_positions"] += int(st.running_candidates) * (int(st.src_tokens_padded) // max(1, B))
+        t["batches"] += 1
         self.model_calls_num += int(st.model_calls)
-        self.model_input_lines_num += int(st.input_lines)
-        self.b_sz += int(st.running_rows)
+        if self.smart_drafts_mode:                                               # only the smart-drafts loop counts these (:741, :760)
+            self.model_input_lines_num += int(st.input_lines)
+            self.b_sz += int(st.running_rows)
         self.accepted_tokens_num += int(st.accepted_tokens)
         self.produced_non_pad_tokens += int(st.produced_non_pad_tokens)
         if not self.smart_drafts_mode:

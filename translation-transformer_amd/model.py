@@ -195,33 +195,6 @@ class NativeTransformer:
                                           top.data_ptr(), idx.data_ptr(), self._stream()))
         return top, idx.reshape(-1)
 
-    def beam_expand(self, cl, chosen, best_n, logp, cand, length, chosen_slot, finished, B, beam, K, pad, bos, eos):
-        """One iteration's candidate expansion (ttx_beam_expand).  Returns (new_cand Long[B*K,width], new_logp, parent Long,
-        parent_draft Long, mark Long, summary list[5])."""
-        dev = self.device
-        n_cand, dl1, V = cl.shape
-        dl = dl1 - 1
-        cl = cl.to(dev, torch.float32).contiguous()
-        chosen = chosen.to(dev, torch.int64).contiguous()
-        best_n = best_n.to(dev, torch.int64).contiguous()
-        logp = logp.to(dev, torch.float32).contiguous()
-        cand = cand.to(dev, torch.int64).contiguous()
-        length = length.to(dev, torch.int32).contiguous()
-        chosen_slot = chosen_slot.to(dev, torch.int32).contiguous()
-        finished = finished.to(dev, torch.uint8).contiguous()
-        width = cand.shape[1]
-        new_cand = torch.empty((B * K, width), dtype=torch.int64, device=dev)
-        new_logp = torch.empty(B * K, dtype=torch.float32, device=dev)
-        parent = torch.empty(B * K, dtype=torch.int32, device=dev)
-        pdraft = torch.empty(B * K, dtype=torch.int32, device=dev)
-        mark = torch.empty(B * K, dtype=torch.int32, device=dev)
-        summary = (C.c_int32 * 5)()
-        N.check(self._lib.ttx_beam_expand(self._session, cl.data_ptr(), chosen.data_ptr(), best_n.data_ptr(), logp.data_ptr(),
-                                          cand.data_ptr(), width, length.data_ptr(), chosen_slot.data_ptr(), finished.data_ptr(),
-                                          B, beam, dl, V, K, pad, bos, eos, new_cand.data_ptr(), new_logp.data_ptr(),
-                                          parent.data_ptr(), pdraft.data_ptr(), mark.data_ptr(), summary, self._stream()))
-        return new_cand, new_logp, parent.long(), pdraft.long(), mark.long(), list(summary)
-
     def make_drafts(self, src: torch.Tensor, draft_len: int, n_drafts: int, min_draft_len: int, max_draft_len: int,
                     eos_token_idx: int, pad_token_idx: int, replace_token_idx: int) -> torch.Tensor:
         """src/utils/drafting.py:5-67 on the device."""
