@@ -148,6 +148,61 @@ def flops_and_bytes(cfg: dict, stats: dict, B_total_src_tokens: int, n_batches: 
     return {"gemm_flops": float(gemm_flops), "bytes": float(bytes_total), "gemm_bytes": float(gemm_bytes)}
 
 
+class _SynthTokenizer:
+    """The attributes of the reference's tokenizer the Lightning module reads (tokenizer_base.py:16-40)."""
+
+    def __init__(self, ids, vocab):
+        self.pad_token_idx, self.bos_token_idx, self.eos_token_idx, c_tok = ids
+        self.n_tokens = vocab
+        self.encoder_dict = {"c": c_tok}
+
+
+def predict_surface(tta, sd, timed, warm, a, outs, raised, toks) -> dict:
+    PAD, BOS, EOS, C_TOK, V = toks
+    from types import SimpleNamespace
+    tk = _SynthTokenizer((PAD, BOS, EOS, C_TOK), V)
+    mod = tta.VanillaEncoderDecoderTransformerLightning(
+        src_tokenizer=tk, tgt_tokenizer=tk, embedding_dim=256, feedforward_dim=2048, num_encoder_layers=4, num_decoder_layers=4,
+        num_heads=8, share_embeddings=True, generation="greedy_speculative", max_len=a.max_len, n_drafts=a.n_drafts,
+        draft_len=a.draft_len, report_prediction_time=False)
+    mod.load_state_dict({"model." + k: v for k, v in sd.items()}, strict=True)
+    mod.cuda()
+    os.environ["TTX_INFLIGHT"] = str(a.inflight)
+
+    def loop(batches):
+        loader = [{"src_tokens": b} for b in batches]
+        mod.trainer = SimpleNamespace(datamodule=None, predict_dataloaders=loader)
+        res = []
+        with torch.inference_mode():
+            mod.on_predict_start()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i, batch in enumerate(loader):
+                try:
+                    res.append(mod.predict_step(batch, i))
+                except tta.ReferenceError_:
+                    res.append(None)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            mod.on_predict_end()
+        return res, dt
+
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the module prints its generator like the reference (lightning_model.py:73)
+        loop((warm * (-(-len(timed) // max(1, len(warm)))))[:len(timed)])    # sessions, workspaces and graphs of this module warm
+        res, dt = loop(timed)
+    ok = [i for i, o in enumerate(res) if o is not None]
+    n = sum(int(timed[i].shape[0]) for i in ok)
+    return {"value": n / dt, "unit": "reactions/s", "window_batches": mod.predict_window,
+            "batches_served_from_look_ahead": mod._ahead.served if mod._ahead is not None else 0,
+            "look_ahead_windows": mod._ahead.windows if mod._ahead is not None else 0,
+            "look_ahead_decode_seconds": mod._ahead.decode_seconds if mod._ahead is not None else 0.0, "loop_seconds": dt,
+            "row_schedule_ran": "device" in mod.generator.stats_total,
+            "identical_to_timed_outputs": sorted(set(range(len(timed))) - set(ok)) == sorted(raised)
+            and all(torch.equal(res[i], outs[i]) for i in ok),
+            "model_calls": mod.generator.model_calls_num}
+
+
 def beam_work(cfg: dict, st: dict, model_calls: int, positions_key: str) -> dict:
     """Algorithmic work of the KV-cached beam-speculative loop (SURVEY.md §8(d) formulas): GEMM FLOPs over the verified
     positions and the encoder tokens; HBM bytes = weights once per iteration / per batch + K/V reads + K/V writes."""
@@ -511,6 +566,11 @@ def main():
                                                   "model_calls": g2.model_calls_num}
             line["device_model_calls"] = stats["device"]["model_calls"]
             line["device_src_tokens_padded"] = stats["device"]["src_tokens_padded"]
+        if not a.timed_only:
+            # The same K batches through the kept Lightning surface (src/model/lightning_model.py:209-243): a trainer
+            # stand-in that only calls on_predict_start -> predict_step per batch -> on_predict_end, i.e. what main.py's
+            # Trainer.predict does; predict_step serves the batches from windows decoded ahead (slot pools).
+            line["predict_step_surface"] = predict_surface(tta, sd, timed, warm, a, outs, raised, (PAD, BOS, EOS, C_TOK, V))
         if not a.no_profile:
             # dominant kernel = k_gemm_tn (fp32 MFMA GEMM): HIP events on the launch stream around every launch,
             # same batches, same process, right after the timed region

@@ -300,7 +300,14 @@ struct ttx_session {
   std::map<GraphKey, hipGraphExec_t> graphs;
   std::set<GraphKey> warmed;
   hipEvent_t ev_done = nullptr;
-  void drop_graphs() { for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second); graphs.clear(); warmed.clear(); }
+  std::map<std::vector<int>, hipGraphExec_t> beam_graphs;   // one iteration of the beam-speculative loop per shape
+  std::set<std::vector<int>> beam_warmed;
+  void drop_graphs() {
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    graphs.clear(); warmed.clear();
+    for (auto& kv : beam_graphs) (void)hipGraphExecDestroy(kv.second);
+    beam_graphs.clear(); beam_warmed.clear();
+  }
   void graphs_current() { if (graphs_generation != alloc_generation) { drop_graphs(); graphs_generation = alloc_generation; } }
   DecState* host_state = nullptr;  // pinned copy target
   bool attn_attr_set = false;
@@ -1966,16 +1973,15 @@ __global__ void k_bs_src_of(int* src_of, int n, int beam) {
   if (i < n) src_of[i] = i / beam;
 }
 
-// Enqueue one iteration (the loop condition of :464 / :652 was checked by the caller).
-static int beam_launch_iter(BeamJob& j) {
+// The kernels of one iteration, in order, as a function of the job's scalars alone (so that the sequence can be captured
+// once per shape and replayed).  `first`: no cache to derive (every candidate is a fresh <BOS> row); `cur`: which of the
+// two cache buffers holds the parents' caches.
+static int beam_enqueue_iter(const BeamJob& j, bool first, int cur) {
   ttx_session* s = j.s;
   hipStream_t st = j.st;
   const ttx_model* m = s->m;
   const ttx_config& c = m->cfg;
   const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
-  j.dl = std::min(j.room, j.dl);                                   // :476
-  const int grow = j.dl + 1 - j.empty_cols;
-  if (grow > 0) j.width += grow;
   const int dl = j.dl, MC = j.max_cand;
   const long long cache_seq = (long long)j.Lc * d, cache_layer = (long long)MC * cache_seq;
   BeamPrepArgs pa{};
@@ -1991,12 +1997,12 @@ static int beam_launch_iter(BeamJob& j) {
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_bs_src_of, dim3(cdiv(MC, 256)), dim3(256), 0, st, s->t_src_of.as<int>(), MC, j.beam);
   HIP_TRY(hipGetLastError());
-  const int nxt = j.cur ^ 1;
-  if (j.launched > 0) {
+  const int nxt = cur ^ 1;
+  if (!first) {
     TreeCacheArgs ca{};
     ca.len = s->bs_len.as<int>(); ca.parent = s->bs_parent.as<int>(); ca.parent_draft = s->bs_parent_draft.as<int>();
     ca.prev_len = s->t_prev_len.as<int>(); ca.active = s->bs_active.as<uint8_t>();
-    ca.k_old = s->tk[j.cur].as<float>(); ca.v_old = s->tv[j.cur].as<float>();
+    ca.k_old = s->tk[cur].as<float>(); ca.v_old = s->tv[cur].as<float>();
     ca.k_new = s->tk[nxt].as<float>(); ca.v_new = s->tv[nxt].as<float>();
     ca.cache_layer_stride = cache_layer; ca.cache_seq_stride = cache_seq;
     ca.qkv_prev = s->qkv.as<float>();
@@ -2005,7 +2011,6 @@ static int beam_launch_iter(BeamJob& j) {
     hipLaunchKernelGGL(k_tree_cache, dim3(MC, Ld), dim3(256), 0, st, ca);
     HIP_TRY(hipGetLastError());
   }
-  j.cur = nxt;
   BeamListArgs la{};
   la.active = s->bs_active.as<uint8_t>(); la.per_cand = s->bs_per_cand.as<int>(); la.len = s->bs_len.as<int>();
   la.n_cand = j.n_cand; la.N = j.N; la.dl = dl;
@@ -2016,7 +2021,7 @@ static int beam_launch_iter(BeamJob& j) {
   // the verify step: D+1 new positions per (running candidate, draft slot) on the candidate's KV cache
   StepCtx k{};
   k.B = MC; k.Ls = j.Ls; k.N = j.N; k.D = dl; k.Lc = j.Lc; k.gen_ld = j.gen_ld; k.max_len = j.p.max_len;
-  k.kcache = s->tk[j.cur].as<float>(); k.vcache = s->tv[j.cur].as<float>(); k.src_of = s->t_src_of.as<int>(); k.want_argmax = false;
+  k.kcache = s->tk[nxt].as<float>(); k.vcache = s->tv[nxt].as<float>(); k.src_of = s->t_src_of.as<int>(); k.want_argmax = false;
   {
     struct PolicyScope {          // few hundred step rows: the small-batch GEMM policy, as ttx_tree_step
       ttx_session* s; int g3, ps, fs, bt;
@@ -2056,10 +2061,54 @@ static int beam_launch_iter(BeamJob& j) {
   HIP_TRY(hipGetLastError());
   BeamHost* dev_host = nullptr;
   HIP_TRY(hipHostGetDevicePointer((void**)&dev_host, (void*)s->beam_host, 0));
-  ++j.launched;
-  hipLaunchKernelGGL(k_bs_publish, dim3(1), dim3(64), 0, st, s->beam_summary.as<int>(), dev_host, j.launched);
+  hipLaunchKernelGGL(k_bs_publish, dim3(1), dim3(64), 0, st, s->beam_summary.as<int>(), dev_host, s->bs_cnt.as<BeamCounters>());
   HIP_TRY(hipGetLastError());
-  j.prev_dl = dl;
+  return TTX_OK;
+}
+
+// Enqueue one iteration (the loop condition of :464 / :652 was checked by the caller): replay the captured graph of this
+// shape, capturing it on its second use (the first use runs eagerly: function attributes are set outside capture).
+static int beam_launch_iter(BeamJob& j) {
+  ttx_session* s = j.s;
+  j.dl = std::min(j.room, j.dl);                                   // :476
+  const int grow = j.dl + 1 - j.empty_cols;
+  if (grow > 0) j.width += grow;
+  const bool first = j.launched == 0;
+  const int cur = j.cur;
+  const int kcap = std::min(j.p.max_len, ((j.width + 63) / 64) * 64);
+  int rc = TTX_OK;
+  if (!s->use_graphs || s->profile) {
+    rc = beam_enqueue_iter(j, first, cur);
+  } else {
+    s->graphs_current();
+    const std::vector<int> key{j.B, j.Ls, j.K, j.N, j.D0, j.smart ? 1 : 0, j.p.max_len, j.n_cand, j.beam, j.dl, j.prev_dl, cur, kcap,
+                               first ? 1 : 0, j.p.pad_token, j.p.bos_token, j.p.eos_token};
+    auto it = s->beam_graphs.find(key);
+    if (it == s->beam_graphs.end() && !s->beam_warmed.count(key)) {
+      s->beam_warmed.insert(key);
+      rc = beam_enqueue_iter(j, first, cur);
+    } else {
+      if (it == s->beam_graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(hipStreamBeginCapture(j.st, hipStreamCaptureModeThreadLocal));
+        rc = beam_enqueue_iter(j, first, cur);
+        hipError_t e = hipStreamEndCapture(j.st, &graph);
+        if (rc != TTX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return fail(TTX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return fail(TTX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        if (s->beam_graphs.size() > 256) s->drop_graphs();
+        it = s->beam_graphs.emplace(key, exec).first;
+      }
+      HIP_TRY(hipGraphLaunch(it->second, j.st));
+    }
+  }
+  TTX_TRY(rc);
+  ++j.launched;
+  j.cur = cur ^ 1;
+  j.prev_dl = j.dl;
   j.any_iteration = true;
   j.last_progress = std::chrono::steady_clock::now();
   j.idle_spins = 0;

@@ -2800,11 +2800,13 @@ __global__ __launch_bounds__(256) void k_bs_leaves(BeamLeaves2Args a) {
                    a.leaf_score, a.leaf_tok, a.leaf_cnt, lp_kept);
 }
 
-__global__ void k_bs_publish(const int* summary, BeamHost* host, int iter) {
+// Last kernel of an iteration: the selection summary and the iteration count go to the pinned words the host polls (the
+// count comes from the device-side counter so that the kernel's arguments are the same in every iteration: graph replay).
+__global__ void k_bs_publish(const int* summary, BeamHost* host, const BeamCounters* cnt) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     for (int i = 0; i < 5; ++i) host->summary[i] = summary[i];
     __threadfence_system();
-    host->steps_done = iter;
+    host->steps_done = (int)cnt->model_calls;
     __threadfence_system();
   }
 }

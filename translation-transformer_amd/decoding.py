@@ -37,6 +37,7 @@ class TranslationInferenceGreedySpeculative:
                             "kv_prefix_positions": 0, "src_positions": 0, "encode_ms": 0.0, "decode_ms": 0.0,
                             "src_tokens_padded": 0, "batches": 0}
         self.last_stats: N.GenStats | None = None
+        self.last_failed_batches: list = []    # generate_many(on_error="skip"): batches on which the reference raises
         self.record_step = 0           # parity tests: k > 0 keeps the logits of verify step k (see step_snapshot)
 
     def step_snapshot(self) -> dict:
@@ -154,7 +155,7 @@ class TranslationInferenceGreedySpeculative:
         # device group size: the given batch size is not binding any more; larger groups run the GEMMs at better MFMA
         # occupancy, but at least `in_flight` groups should exist so that tails overlap
         if pool:      # slot pool: about 2 048 slots in flight in total (512 x 4 measured best)
-            gsz = int(group_size or 512)
+            gsz = int(group_size or os.environ.get("TTX_POOL_CAPACITY") or 512)
         else:
             gsz = int(group_size or min(256, max(max(sizes), -(-R // max(1, in_flight)))))
         self.last_group_size = gsz
@@ -180,6 +181,8 @@ class TranslationInferenceGreedySpeculative:
             # continuous batching: every session keeps `gsz` slots filled from the sorted work list
             # (ttx_greedy_speculative_generate_pool)
             n_sess = max(1, min(in_flight, max(1, 2048 // gsz), -(-R // 32)))     # short lists: several small pools overlap
+            if os.environ.get("TTX_POOL_SESSIONS"):                               # experiments
+                n_sess = max(1, int(os.environ["TTX_POOL_SESSIONS"]))
             sessions = m.session_pool(n_sess)
             sess = (C.c_void_p * len(sessions))(*[q.value for q in sessions])
             width = max(2, int(sorted_len[0]))
@@ -254,8 +257,9 @@ class TranslationInferenceGreedySpeculative:
         out_rows = torch.where(keep.to(m.device)[:, None], out_rows, torch.full_like(out_rows, self.pad_token))
         if os.environ.get("TTX_HOST_PROFILE"):
             torch.cuda.synchronize()
+            import sys as _sys
             print(f"[ttx rows] prepare+device {1e3 * (_t1 - _t0):.1f} ms, replay+scatter {1e3 * (_time.perf_counter() - _t1):.1f} ms",
-                  flush=True)
+                  file=_sys.stderr, flush=True)
         outs, r0 = [], 0
         skipped = set(self.last_failed_batches)
         for bi, B in enumerate(sizes):

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import datetime
 import json
+import os
 from pathlib import Path
 from timeit import default_timer as timer
 from types import SimpleNamespace
@@ -74,6 +75,70 @@ class WeightContainer(nn.Module):
         raise RuntimeError("the torch modules here only hold parameters; the forward pass runs in libttx_hip.so")
 
 
+class _PredictAhead:
+    """Decodes windows of the predict dataloader ahead of ``predict_step`` so that the rows of many batches share the
+    GPU (slot pools for greedy-speculative: generate_many(reorder=True); batches in flight for beam-speculative), while
+    ``Trainer.predict`` / ``main.py`` keep calling ``predict_step(batch, batch_idx)`` one batch at a time.
+
+    The reference's loop decodes batch i inside predict_step(i) (src/model/lightning_model.py:209-212).  Here the module
+    walks a second iterator over the same (unshuffled: src/data_handling/seq2seq_wrappers.py:168-175) dataloader, `window`
+    batches at a time; predict_step(i) checks that the batch it was handed holds exactly the tokens that were decoded for
+    index i and returns that tensor — identical to generate(batch) (row-scheduled decoding replays the reference's loop per
+    given batch).  Any mismatch (a sampler that reorders, a dataloader that cannot be iterated twice) switches the
+    look-ahead off for the rest of the run and the batch is decoded on the spot.  A batch on which the reference raises is
+    left to generate() so that the error surfaces at the same predict_step as in the reference."""
+
+    def __init__(self, generator, loader, window: int, in_flight: int):
+        self.generator, self.window, self.in_flight = generator, max(1, int(window)), max(1, int(in_flight))
+        self.it = iter(loader)
+        self.next_idx = 0            # index of the next batch the iterator yields
+        self.ready = {}              # batch index -> (src tokens on the device, prediction or None)
+        self.enabled = True
+        self.served = self.fallbacks = self.windows = 0
+        self.decode_seconds = 0.0
+
+    def _decode_window(self, device) -> None:
+        pending = []
+        for _ in range(self.window):
+            try:
+                b = next(self.it)
+            except StopIteration:
+                break
+            pending.append(b["src_tokens"].to(device))
+        if not pending:
+            self.enabled = False
+            return
+        g = self.generator
+        t0 = timer()
+        if isinstance(g, D.TranslationInferenceGreedySpeculative):      # slot pools over all rows of the window
+            preds = g.generate_many(pending, in_flight=self.in_flight, reorder=True, on_error="skip")
+        else:
+            preds = g.generate_many(pending, in_flight=self.in_flight)
+        self.decode_seconds += timer() - t0
+        self.windows += 1
+        for k, (src, pred) in enumerate(zip(pending, preds)):
+            self.ready[self.next_idx + k] = (src, pred)
+        self.next_idx += len(pending)
+
+    def take(self, src: torch.Tensor, batch_idx: int):
+        """The prediction prepared for batch `batch_idx`, or None (decode it now)."""
+        if not self.enabled:
+            return None
+        if batch_idx not in self.ready and batch_idx == self.next_idx:
+            self._decode_window(src.device)
+        hit = self.ready.pop(batch_idx, None)
+        if hit is None or hit[0].shape != src.shape or not torch.equal(hit[0], src.to(hit[0].device)):
+            self.enabled = False                       # not the batch that was decoded for this index: stop looking ahead
+            self.ready.clear()
+            self.fallbacks += 1
+            return None
+        if hit[1] is None:                             # the reference raises on this batch: let generate() raise it here
+            self.fallbacks += 1
+            return None
+        self.served += 1
+        return hit[1]
+
+
 class VanillaEncoderDecoderTransformerLightning(LightningModule):
     def __init__(self,
                  src_tokenizer=None, tgt_tokenizer=None,
@@ -105,12 +170,26 @@ class VanillaEncoderDecoderTransformerLightning(LightningModule):
             assert draft_len > 0, "Number of speculative tokens must be a positive integer."
         self.native: NativeTransformer | None = None
         self.generator = None
+        self._ahead = None
+        # batches decoded ahead of predict_step (0: decode every batch inside its own predict_step like the reference);
+        # not an init_arg, so the reference's YAML files load unchanged — set the attribute or TTX_PREDICT_WINDOW
+        self.predict_window = 256
         self.report_prediction_time = report_prediction_time
         self.prediction_start_time = None
 
     # -- native path ------------------------------------------------------------------------------
-    def build_native(self, device: int | str | torch.device | None = None) -> None:
-        """(Re)build the HIP model + generator from the current parameters (call after loading a checkpoint)."""
+    def _weights_fingerprint(self) -> tuple:
+        return tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in self.model.parameters())
+
+    def build_native(self, device: int | str | torch.device | None = None, force: bool = False) -> None:
+        """(Re)build the HIP model + generator from the current parameters (call after loading a checkpoint).  A second
+        call with untouched parameters (same storage, same version counters) keeps the HIP model and its warm sessions and
+        only makes a fresh generator (zeroed counters)."""
+        fp = self._weights_fingerprint()
+        if not force and self.native is not None and fp == getattr(self, "_native_fp", None) and device is None:
+            self.generator = self._create_generator()
+            print(self.generator)
+            return
         if device is None:
             p = next(self.model.parameters())
             device = p.device if p.is_cuda else torch.device("cuda:0")
@@ -120,6 +199,7 @@ class VanillaEncoderDecoderTransformerLightning(LightningModule):
             raise ValueError(f"source pad id {self.src_pad_token_i} != target pad id {self.tgt_pad_token_i}: the HIP path "
                              "supports one shared pad index (the reference's tokenizers fix PAD=0, tokenizer_base.py:27)")
         self.native = NativeTransformer(self.model.state_dict(), self.hparams.num_heads, self.tgt_pad_token_i, device=device)
+        self._native_fp = fp
         self.generator = self._create_generator()
         print(self.generator)
 
@@ -141,10 +221,38 @@ class VanillaEncoderDecoderTransformerLightning(LightningModule):
     def predict_step(self, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> Any:
         if self.generator is None:
             self.build_native()
+        ahead = self._ahead
+        if ahead is not None and dataloader_idx == 0:
+            pred = ahead.take(batch["src_tokens"], batch_idx)
+            if pred is not None:
+                return pred
         return self.generator.generate(batch["src_tokens"])
+
+    def _predict_loader(self):
+        """The (first) predict dataloader Trainer.predict iterates, or None."""
+        tr = self.trainer
+        if tr is None:
+            return None
+        loaders = getattr(tr, "predict_dataloaders", None)
+        if loaders is None:
+            dm = getattr(tr, "datamodule", None)
+            loaders = dm.predict_dataloader() if dm is not None and hasattr(dm, "predict_dataloader") else None
+        if loaders is None:
+            return None
+        if isinstance(loaders, (list, tuple)):
+            if len(loaders) == 0:
+                return None
+            return loaders if isinstance(loaders[0], dict) else loaders[0]     # a list of batches is a loader itself
+        return loaders
 
     def on_predict_start(self) -> None:
         self.build_native()                      # weights are final here (Trainer.predict has loaded --ckpt_path)
+        self._ahead = None
+        window = int(os.environ.get("TTX_PREDICT_WINDOW", str(self.predict_window)))
+        if window > 0 and hasattr(self.generator, "generate_many"):
+            loader = self._predict_loader()
+            if loader is not None:
+                self._ahead = _PredictAhead(self.generator, loader, window, int(os.environ.get("TTX_INFLIGHT", "8")))
         if self.report_prediction_time:
             self.prediction_start_time = timer()
 
@@ -186,45 +294,31 @@ class VanillaEncoderDecoderTransformerLightning(LightningModule):
 
 
 def run_predict(module: VanillaEncoderDecoderTransformerLightning, batches, writer=None, datamodule=None,
-                schedule: str = "batches", window: int = 256, in_flight: int = 8) -> list:
-    """Stand-in for ``Trainer.predict`` when pytorch_lightning is absent: same hook order
-    (on_predict_start -> predict_step per batch -> writer.write_on_batch_end -> on_predict_end).
-
-    ``schedule="rows"`` (greedy_speculative only) takes `window` batches at a time, decodes their rows in
-    length-sorted device groups (generate_many(reorder=True): outputs and model_calls per given batch are those of
-    predict_step) and then hands the batches to the writer in their original order.  The only observable difference
-    to the per-batch loop: if the reference would raise on some batch, the error surfaces before the batches of
-    that window have been written instead of after the preceding ones."""
+                schedule: str = "rows", window: int = 256, in_flight: int = 8) -> list:
+    """Stand-in for ``Trainer.predict`` when pytorch_lightning is absent: the same hook order and nothing else
+    (on_predict_start -> predict_step per batch -> writer.write_on_batch_end -> on_predict_end), with a trainer object that
+    exposes ``predict_dataloaders`` and ``datamodule`` like Lightning's.  ``schedule="batches"`` switches the module's
+    look-ahead off (every batch is decoded inside its own predict_step, as in the reference)."""
     if schedule not in ("batches", "rows"):
         raise ValueError("schedule must be 'batches' or 'rows'")
-    module.trainer = SimpleNamespace(datamodule=datamodule)
+    batches = list(batches)
+    module.trainer = SimpleNamespace(datamodule=datamodule, predict_dataloaders=batches)
+    module.predict_window = window if schedule == "rows" else 0
+    old_inflight = os.environ.get("TTX_INFLIGHT")
+    os.environ["TTX_INFLIGHT"] = str(in_flight)
     outs = []
-    with torch.inference_mode():
-        module.on_predict_start()
-        if schedule == "rows" and hasattr(module.generator, "generate_many"):
-            pending = []
-
-            def flush(first_idx):
-                preds = module.generator.generate_many([b["src_tokens"] for b in pending], in_flight=in_flight, reorder=True)
-                for k, (b, pred) in enumerate(zip(pending, preds)):
-                    if writer is not None:
-                        writer.write_on_batch_end(module.trainer, module, pred, None, b, first_idx + k, 0)
-                    outs.append(pred)
-                pending.clear()
-
-            first = 0
-            for i, batch in enumerate(batches):
-                pending.append(batch)
-                if len(pending) == window:
-                    flush(first)
-                    first = i + 1
-            if pending:
-                flush(first)
-        else:
+    try:
+        with torch.inference_mode():
+            module.on_predict_start()
             for i, batch in enumerate(batches):
                 pred = module.predict_step(batch, i)
                 if writer is not None:
                     writer.write_on_batch_end(module.trainer, module, pred, None, batch, i, 0)
                 outs.append(pred)
-        module.on_predict_end()
+            module.on_predict_end()
+    finally:
+        if old_inflight is None:
+            os.environ.pop("TTX_INFLIGHT", None)
+        else:
+            os.environ["TTX_INFLIGHT"] = old_inflight
     return outs
