@@ -250,8 +250,8 @@ def main_beam(a):
     from tools.synth import SynthReactions, batches, PAD, BOS, EOS, C_TOK, V
 
     setup = {}
-    sd = tta.dist.broadcast_state_dict(get_weights(a.train_steps, dev, bc["kind"], bc["layers"], setup) if rank == 0 else None, dev, dist)
-    model = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=PAD, device=local_rank)
+    sd = get_weights(a.train_steps, dev, bc["kind"], bc["layers"], setup) if rank == 0 else None
+    model = tta.dist.broadcast_model(sd, 8, PAD, local_rank, dist)
     cfg = {"d": model.emb_dim, "F": model.ff_dim, "V": model.tgt_vocab_size, "Le": model.num_enc_layers, "Ld": model.num_dec_layers}
     assert cfg["Le"] == bc["layers"] and cfg["Ld"] == bc["layers"]
     per_rank = (a.steps + a.warmup) * a.batch_size
@@ -434,10 +434,11 @@ def main():
     import translation_transformer_amd as tta
     from tools.synth import SynthReactions, batches, PAD, BOS, EOS, C_TOK, V
 
-    # ---- weights: rank 0 trains/loads, one RCCL broadcast of the packed fp32 blob
+    # ---- weights: rank 0 trains/loads and packs them into its HBM blob; every other rank receives that blob with ONE RCCL
+    # broadcast straight into its own (empty) model's blob (dist.broadcast_model)
     setup = {}
-    sd = tta.dist.broadcast_state_dict(get_weights(a.train_steps, dev, info=setup) if rank == 0 else None, dev, dist)
-    model = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=PAD, device=local_rank)
+    sd = get_weights(a.train_steps, dev, info=setup) if rank == 0 else None
+    model = tta.dist.broadcast_model(sd, 8, PAD, local_rank, dist)      # one RCCL broadcast of the packed blob into HBM
     cfg = {"d": model.emb_dim, "F": model.ff_dim, "V": model.tgt_vocab_size, "Le": model.num_enc_layers,
            "Ld": model.num_dec_layers}
 
@@ -500,6 +501,8 @@ def main():
     gathered = tta.dist.gather_predictions(preds.unsqueeze(1), world * preds.shape[0], dist)
     if rank == 0:
         assert gathered.shape[0] == world * preds.shape[0]
+        if os.environ.get("TTX_DUMP_PREDICTIONS"):        # tests/test_gpu_dist.py compares them with a single-process decode
+            np.save(os.environ["TTX_DUMP_PREDICTIONS"], gathered.cpu().numpy())
     counted = tta.dist.sum_counters({"reactions": sum(int(timed[i].shape[0]) for i in range(len(timed)) if i not in raised),
                                      "raised": len(raised)}, dev, dist)
     n_reactions = int(counted["reactions"])

@@ -1,0 +1,123 @@
+"""Multi-GPU layer on the GPU box: C1 — an EMPTY model plus the packed weight blob IS the model (what a
+non-source rank holds after the one RCCL broadcast); the broadcast itself over RCCL (world size 1: the box has one GPU); and
+the N = 2 data path of bench.py as two fresh processes sharing GPU 0 (gloo collectives: RCCL refuses two ranks on one
+device), gathered predictions compared with a single-process decode of the same rows."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from util_models import tiny_state, fixture_tokens, PAD, BOS, EOS
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_empty_model_plus_blob_is_the_model():
+    import translation_transformer_amd as tta
+    from translation_transformer_amd.model import shape_of_state
+    st, cfg = tiny_state()
+    a = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    b = tta.NativeTransformer(None, cfg["num_heads"], 0, device=0, shape=shape_of_state(st))
+    ba, bb = a.blob_tensor(), b.blob_tensor()
+    assert ba.shape == bb.shape and ba.dtype == torch.float32 and ba.is_cuda
+    bb.copy_(ba)                                   # what the broadcast does on a receiving rank
+    torch.cuda.synchronize()
+    src, _, c, _ = fixture_tokens()
+    s = src[:6].cuda()
+    ma, mb = a.encode_src(s), b.encode_src(s)
+    assert torch.equal(ma, mb)
+    tgt = src[:6, :20].cuda()
+    assert torch.equal(a.decode_tgt(tgt, ma, s == PAD), b.decode_tgt(tgt, mb, s == PAD))
+    ga = tta.TranslationInferenceGreedySpeculative(a, 150, 10, 3, PAD, BOS, EOS, c).generate(s)
+    gb = tta.TranslationInferenceGreedySpeculative(b, 150, 10, 3, PAD, BOS, EOS, c).generate(s)
+    assert torch.equal(ga, gb) and bool((ga == EOS).any(dim=2).all())
+
+
+CHILD_RCCL = r"""
+import os, sys, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import torch.distributed as dist
+import translation_transformer_amd as tta
+from util_models import tiny_state, fixture_tokens, PAD, BOS, EOS
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)          # "nccl" is RCCL on ROCm
+st, cfg = tiny_state()
+m = tta.dist.broadcast_model(st, cfg["num_heads"], 0, 0, dist)
+blob = m.blob_tensor()
+dist.broadcast(blob, src=0)                                    # the collective runs on the library's own allocation
+torch.cuda.synchronize()
+src, _, c, _ = fixture_tokens()
+out = tta.TranslationInferenceGreedySpeculative(m, 150, 10, 3, PAD, BOS, EOS, c).generate(src[:4].cuda())
+ref = tta.TranslationInferenceGreedySpeculative(tta.NativeTransformer(st, cfg["num_heads"], 0, device=0), 150, 10, 3, PAD, BOS, EOS, c).generate(src[:4].cuda())
+assert torch.equal(out, ref)
+dist.destroy_process_group()
+print("rccl blob broadcast ok", int(blob.numel()))
+"""
+
+
+def test_blob_broadcast_over_rccl():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", CHILD_RCCL % {"root": str(ROOT), "tests": str(ROOT / "tests")}], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rccl blob broadcast ok" in r.stdout
+
+
+def test_two_rank_bench_data_path_equals_single_process(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), here with both ranks on GPU 0:
+    shard bounds, weight broadcast, per-rank decode through the slot pools, prediction gather, counter sums.  The gathered
+    predictions must equal a single-process per-batch decode of the same rows with the same weights."""
+    import translation_transformer_amd as tta
+    sys.path.insert(0, str(ROOT))
+    from tools.synth import SynthReactions, batches, PAD as SPAD, BOS as SBOS, EOS as SEOS, C_TOK
+    from tools.train_synth import train
+    weights = ROOT / ".weights_cache" / "synth_mit_1500.pt"       # bench.py's own cache (shipped with the snapshot, git-ignored)
+    trained = weights.exists()
+    if not trained:                                               # clean clone: a short training run gives usable weights
+        weights = tmp_path / "w.pt"
+        torch.save(train("mit", steps=200, device="cuda", verbose=False, n_train=4000), weights)
+    steps, warmup, bs, world = 3, 1, 32, 2
+    dump = tmp_path / "gathered.npy"
+    env = dict(os.environ, TTX_SHARE_GPU="1", TTX_DIST_BACKEND="gloo", TTX_WEIGHTS=str(weights), TTX_DUMP_PREDICTIONS=str(dump),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup",
+           str(warmup), "--timed-only"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["config"]["reactions"] == world * steps * bs
+    got = np.load(dump)
+    assert got.shape == (world * steps * bs, 1, 200)
+    # the same rows, one process, one batch at a time
+    sd = torch.load(weights, weights_only=True, map_location="cpu")
+    model = tta.NativeTransformer(sd, 8, SPAD, device=0)
+    per_rank = (steps + warmup) * bs
+    src_all, _ = SynthReactions(123456, "mit").dataset(per_rank * world)
+    exp = []
+    for rank in range(world):
+        mine = src_all[rank * per_rank:(rank + 1) * per_rank]
+        for b in list(batches(mine, bs))[warmup:]:
+            g = tta.TranslationInferenceGreedySpeculative(model, 200, 10, 3, SPAD, SBOS, SEOS, C_TOK)
+            try:
+                exp.append(g.generate(torch.from_numpy(b).cuda()).cpu().numpy())
+            except tta.ReferenceError_:
+                exp.append(np.full((b.shape[0], 1, 200), SPAD, dtype=np.int64))
+    exp = np.concatenate(exp)
+    np.testing.assert_array_equal(got, exp)
+    finished = int((exp == SEOS).any(axis=2).sum())
+    print(f"two-rank rehearsal: {finished}/{exp.shape[0]} rows decode to EOS (weights: {'1500-step cache' if trained else '200 steps'})")
+    assert finished > (0.5 * exp.shape[0] if trained else 0)

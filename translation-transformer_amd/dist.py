@@ -49,6 +49,29 @@ def broadcast_state_dict(state: dict | None, device: torch.device | str, dist=No
     return out
 
 
+def broadcast_model(state: dict | None, num_heads: int, pad_token_idx: int, device, dist=None, src: int = 0):
+    """C1 as SURVEY.md §8(e) words it: rank `src` builds the model from its state dict (weights packed into one HBM blob),
+    every other rank creates an EMPTY model of the same shape (ttx_model_create_empty) and receives the blob with ONE
+    RCCL broadcast straight into HBM (ttx_model_blob) — no host staging, no per-tensor messages.  Returns the
+    NativeTransformer of this rank.  Under gloo (CPU tests, several ranks sharing one GPU) the weights travel as a host
+    state dict instead (broadcast_state_dict) and every rank uploads them."""
+    from .model import NativeTransformer, shape_of_state
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return NativeTransformer(state, num_heads, pad_token_idx, device=device)
+    if dist.get_backend() == "gloo":
+        sd = broadcast_state_dict(state, device, dist, src)
+        return NativeTransformer(sd, num_heads, pad_token_idx, device=device)
+    rank = dist.get_rank()
+    meta = [shape_of_state(state) if rank == src else None]
+    dist.broadcast_object_list(meta, src=src)
+    model = NativeTransformer(state if rank == src else None, num_heads, pad_token_idx, device=device, shape=meta[0])
+    blob = model.blob_tensor()
+    torch.cuda.synchronize(blob.device)           # rank src: the upload of the blob has completed
+    dist.broadcast(blob, src=src)
+    torch.cuda.synchronize(blob.device)
+    return model
+
+
 def gather_predictions(local: torch.Tensor, n_items: int, dist=None, dst: int = 0, pad_value: int = 0):
     """C2.  `local` is this rank's [n_local, N, L] integer predictions for its shard_bounds slice; returns the
     [n_items, N, Lmax] tensor in original order on rank `dst` (None elsewhere).  Token ids travel as int32."""

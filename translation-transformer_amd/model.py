@@ -34,27 +34,51 @@ def _strip(state: dict) -> dict:
     return dict(state)
 
 
+def shape_of_state(state_dict: dict) -> dict:
+    """Model dimensions read off a reference state dict (SURVEY.md §8(b) B6 names)."""
+    st = _strip(state_dict)
+    emb = st["src_token_featurizer.embedding.weight"]
+    return {"emb_dim": int(emb.shape[1]), "src_vocab_size": int(emb.shape[0]),
+            "tgt_vocab_size": int(st["next_token_classifier.weight"].shape[0]),
+            "ff_dim": int(st["transformer.encoder.layers.0.linear1.weight"].shape[0]),
+            "num_enc_layers": 1 + max(int(k.split(".")[3]) for k in st if k.startswith("transformer.encoder.layers.")),
+            "num_dec_layers": 1 + max(int(k.split(".")[3]) for k in st if k.startswith("transformer.decoder.layers."))}
+
+
+class _DeviceSpan:
+    """Exposes a device allocation of the library to torch (``torch.as_tensor``) without copying it."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
 class NativeTransformer:
-    def __init__(self, state_dict: dict, num_heads: int, pad_token_idx: int = 0, device: int | str | torch.device = 0,
-                 max_positions: int = 5000, layer_norm_eps: float = 1e-5):
+    def __init__(self, state_dict: dict | None, num_heads: int, pad_token_idx: int = 0, device: int | str | torch.device = 0,
+                 max_positions: int = 5000, layer_norm_eps: float = 1e-5, shape: dict | None = None):
+        """``state_dict``: the reference's state dict (weights are packed into one HBM blob).  ``state_dict=None`` with
+        ``shape`` (see shape_of_state): an EMPTY model of those dimensions whose blob is filled afterwards — the receiving side
+        of the one-off weight broadcast (dist.broadcast_model)."""
         if not torch.cuda.is_available():
             raise RuntimeError("NativeTransformer needs an MI355X: the HIP path has no CPU fallback")
-        st = _strip(state_dict)
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         self.device = dev
-        emb = st["src_token_featurizer.embedding.weight"]
-        self.emb_dim = int(emb.shape[1])
+        st = _strip(state_dict) if state_dict is not None else None
+        dims = shape_of_state(st) if st is not None else dict(shape)
+        self.emb_dim, self.src_vocab_size, self.tgt_vocab_size = dims["emb_dim"], dims["src_vocab_size"], dims["tgt_vocab_size"]
+        self.ff_dim, self.num_enc_layers, self.num_dec_layers = dims["ff_dim"], dims["num_enc_layers"], dims["num_dec_layers"]
         self.num_heads = int(num_heads)
-        self.src_vocab_size = int(emb.shape[0])
-        self.tgt_vocab_size = int(st["next_token_classifier.weight"].shape[0])
-        self.ff_dim = int(st["transformer.encoder.layers.0.linear1.weight"].shape[0])
-        self.num_enc_layers = 1 + max(int(k.split(".")[3]) for k in st if k.startswith("transformer.encoder.layers."))
-        self.num_dec_layers = 1 + max(int(k.split(".")[3]) for k in st if k.startswith("transformer.decoder.layers."))
         self.src_pad_token_i = int(pad_token_idx)
         self.tgt_pad_token_i = int(pad_token_idx)
         self.cfg = N.Config(self.tgt_vocab_size, self.src_vocab_size, self.emb_dim, self.num_heads, self.ff_dim,
                             self.num_enc_layers, self.num_dec_layers, self.src_pad_token_i, int(max_positions),
                             float(layer_norm_eps))
+        self._lib = N.lib()
+        self._model = C.c_void_p()
+        self._session = C.c_void_p()
+        if st is None:
+            N.check(self._lib.ttx_model_create_empty(C.byref(self.cfg), dev.index or 0, C.byref(self._model)))
+            N.check(self._lib.ttx_session_create(self._model, C.byref(self._session)))
+            return
         host = {k: torch.as_tensor(v).detach().to("cpu", torch.float32).contiguous() for k, v in st.items()}
         host["positional_encoding.pe"] = reference_pe_table(self.emb_dim, max_positions)
         arr = (N.Tensor * len(host))()
@@ -63,11 +87,19 @@ class NativeTransformer:
             name = k.encode()
             keep.append((name, v))
             arr[i] = N.Tensor(name, C.cast(v.data_ptr(), C.POINTER(C.c_float)), v.numel())
-        self._lib = N.lib()
-        self._model = C.c_void_p()
         N.check(self._lib.ttx_model_create(C.byref(self.cfg), arr, len(host), dev.index or 0, C.byref(self._model)))
-        self._session = C.c_void_p()
         N.check(self._lib.ttx_session_create(self._model, C.byref(self._session)))
+
+    def blob_tensor(self) -> torch.Tensor:
+        """The packed weight blob in HBM as a flat fp32 torch tensor sharing the library's memory (ttx_model_blob): every
+        tensor of the state dict plus the derived ones (sinusoid table, packed cross-attention K/V projection).  Writing
+        the blob of another model of the same shape into it (one RCCL broadcast) makes this model that model."""
+        ptr, nbytes = C.c_void_p(), C.c_int64()
+        N.check(self._lib.ttx_model_blob(self._model, C.byref(ptr), C.byref(nbytes)))
+        with torch.cuda.device(self.device):
+            t = torch.as_tensor(_DeviceSpan(int(ptr.value), int(nbytes.value)), device=self.device)
+        t._ttx_owner = self              # the tensor borrows the allocation: keep the model alive with it
+        return t
 
     # -- plumbing ------------------------------------------------------------------------------
     def _stream(self) -> C.c_void_p:
