@@ -251,8 +251,8 @@ int ttx_greedy_speculative_generate_rows(ttx_session** sessions, int n_sessions,
  * groups; every session keeps a pool of up to `capacity` slots and admits the next rows of the work list (encoder,
  * cross K/V, drafts, slot state) whenever at least a quarter of its slots are free, so the verify step keeps
  * close to capacity * (1 + n_drafts * draft_len) rows until the list is exhausted.  d_src int64 [R_total][Ls_all] holds
- * ALL rows right-padded, sorted by length, longest first; h_len (HOST, int32 [R_total]) their lengths (position after
- * the last non-PAD token).  d_out int64 [R_total][max_len], d_traj int16 [R_total][max_len + 1], d_fin_step int32
+ * ALL rows right-padded, in the order they are to be admitted (sorted by length pads least: a chunk of rows is encoded at the
+ * width of its longest row); h_len (HOST, int32 [R_total]) their lengths (position after the last non-PAD token).  d_out int64 [R_total][max_len], d_traj int16 [R_total][max_len + 1], d_fin_step int32
  * [R_total] as in ttx_greedy_speculative_generate_rows, in the order of d_src.  `stats` (zero it first) receives the
  * sums over all sessions; stats->model_calls counts the verify steps the device executed.  Returns
  * TTX_ERR_ROW_REPLAY like the rows call. */

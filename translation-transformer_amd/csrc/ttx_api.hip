@@ -1476,15 +1476,16 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
     return fail(TTX_ERR_INVALID, "bad argument to ttx_greedy_speculative_generate_pool");
   if (R_total == 0) return TTX_OK;
   if (p->max_len > 32000) return fail(TTX_ERR_INVALID, "max_len too large for the int16 trace");
-  // rows must come longest first: the first row fixes the slot width
-  for (int i = 1; i < R_total; ++i)
-    if (h_len[i] > h_len[i - 1]) return fail(TTX_ERR_INVALID, "rows must be sorted by length, longest first");
-  if (h_len[0] > Ls_all) return fail(TTX_ERR_INVALID, "row length beyond the source matrix width");
+  // the longest row fixes the slot width; rows are admitted in the order given (length-sorted lists pad least: a chunk
+  // is encoded at the width of its longest row)
+  int len_max = 0;
+  for (int i = 0; i < R_total; ++i) len_max = std::max(len_max, (int)h_len[i]);
+  if (len_max > Ls_all) return fail(TTX_ERR_INVALID, "row length beyond the source matrix width");
   // slot width: 192 positions, beyond that in steps of 64 — calls whose longest sources differ share workspaces and
   // the captured step graph (a slot's keys are bounded by its own source length, so the padding costs memory only:
   // 0.8 GB of cross K/V per 512-slot pool at 192)
-  int Ls_cap = std::min(std::max(192, (((int)h_len[0] + 63) / 64) * 64), sessions[0]->m->cfg.max_positions);
-  Ls_cap = std::max(Ls_cap, std::max(2, (int)h_len[0]));
+  int Ls_cap = std::min(std::max(192, ((len_max + 63) / 64) * 64), sessions[0]->m->cfg.max_positions);
+  Ls_cap = std::max(Ls_cap, std::max(2, len_max));
   TTX_TRY(gen_validate(sessions[0], d_src, capacity, Ls_cap, p, d_out, false));
   HIP_TRY(hipSetDevice(sessions[0]->m->device));
   release_retired();
@@ -1534,8 +1535,13 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
           int n_running = 0;
           for (const PoolJob& o : jobs) n_running += (o.phase == 1);
           const int remaining = R_total - cursor;
-          const int take = std::min({free_slots, remaining, std::max(1, cdiv(remaining, std::max(1, n_running)))});
-          const int Ls_new = std::max(2, (int)h_len[cursor]);                 // longest of the chunk (rows are sorted)
+          int share = std::max(1, cdiv(remaining, std::max(1, n_running)));
+          // first fill of a list that fits the pools at once: an equal share for every pool not yet started (the pools
+          // before this one have taken theirs), so that nothing is left waiting for a later admission
+          if (j.launched == 0 && (long long)n_jobs * C >= R_total) share = std::max(1, cdiv(remaining, n_jobs - i));
+          const int take = std::min({free_slots, remaining, share});
+          int Ls_new = 2;                                                      // longest row of the chunk
+          for (int r = cursor; r < cursor + take; ++r) Ls_new = std::max(Ls_new, (int)h_len[r]);
           rc_final = pool_admit(j, d_src + (size_t)cursor * Ls_all, Ls_all, take, Ls_new, cursor, d_out, d_traj, d_fin_step);
           if (rc_final != TTX_OK) break;
           cursor += take;

@@ -7,6 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import numpy as np
 import torch
 
 from . import _native as N
@@ -185,7 +186,7 @@ class TranslationInferenceGreedySpeculative:
                 n_sess = max(1, int(os.environ["TTX_POOL_SESSIONS"]))
             sessions = m.session_pool(n_sess)
             sess = (C.c_void_p * len(sessions))(*[q.value for q in sessions])
-            width = max(2, int(sorted_len[0]))
+            width = max(2, int(sorted_len.max()))
             src_mat = sorted_src[:, :width].contiguous() if width <= sorted_src.shape[1] else torch.nn.functional.pad(
                 sorted_src, (0, width - sorted_src.shape[1]), value=self.pad_token).contiguous()
             h_len = (C.c_int32 * R)(*[int(x) for x in sorted_len])
