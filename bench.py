@@ -148,6 +148,22 @@ def flops_and_bytes(cfg: dict, stats: dict, B_total_src_tokens: int, n_batches: 
     return {"gemm_flops": float(gemm_flops), "bytes": float(bytes_total), "gemm_bytes": float(gemm_bytes)}
 
 
+def pmc_traffic_for(key: dict):
+    """HBM-side traffic per GEMM launch for exactly this command, from the committed rocprofv3 --pmc passes
+    (profiles/gemm_pmc_traffic.json: one entry per profiled command, written by tools/pmc_summary.py).  Returns
+    (entry, None) or (None, reason): a figure measured on another workload is never reported."""
+    path = ROOT / "profiles" / "gemm_pmc_traffic.json"
+    try:
+        entries = json.loads(path.read_text())
+    except (OSError, ValueError):
+        return None, "no PMC summary committed (profiles/gemm_pmc_traffic.json missing)"
+    for e in entries:
+        if all(e.get("command_key", {}).get(k) == v for k, v in key.items()):
+            return dict(e, file=f"profiles/{e.get('source_file', 'gemm_pmc_traffic.json')}"), None
+    return None, ("no PMC pass was collected for this command (" + ", ".join(f"{k}={v}" for k, v in key.items()) +
+                  "); profiles/gemm_pmc_traffic.json lists the profiled ones")
+
+
 class _SynthTokenizer:
     """The attributes of the reference's tokenizer the Lightning module reads (tokenizer_base.py:16-40)."""
 
@@ -607,22 +623,21 @@ def main():
                 pstats = dict(pstats["device"], encode_ms=pstats["encode_ms"], decode_ms=pstats["decode_ms"])
             pw = flops_and_bytes(cfg, pstats, pstats["src_tokens_padded"], pstats.get("batches", len(timed)))
             ach = pw["gemm_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-            pmc = {}
-            try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_pmc_traffic.json")) as fh:
-                    pmc = json.load(fh)
-            except OSError:
-                pass
-            line["roofline"] = {"kernel": "k_gemm2 (fp32 v_mfma_f32_32x32x2_f32 GEMMs, every launch of the run: encoder, cross K/V, verify steps)",
+            pmc, pmc_why = pmc_traffic_for({"config": a.config, "steps": len(timed), "warmup": a.warmup, "schedule": a.schedule,
+                                            "inflight": a.inflight, "batch_size": a.batch_size, "n_drafts": a.n_drafts,
+                                            "draft_len": a.draft_len, "max_len": a.max_len})
+            line["roofline"] = {"kernel": "k_gemm24<NT> / k_gemm2<NT> (fp32 v_mfma_f32_32x32x2_f32 GEMM family: 128x128 or 64x64 tiles picked "
+                                          "per launch from the live row count; every GEMM launch of the pass: encoder, cross K/V, verify steps)",
                                 "bound": "mfma", "achieved": ach,
                                 "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
-                                "traffic": pmc.get("bytes_per_launch"), "launches": launches,
-                                "traffic_note": ("HBM-side bytes per GEMM launch (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included) "
-                                                 "from the committed rocprofv3 --pmc passes of this command: profiles/r01_gemm_pmc_traffic.json")
-                                                if pmc else "no PMC file",
+                                "traffic": pmc.get("bytes_per_launch") if pmc else None, "launches": launches,
+                                "traffic_note": (f"HBM-side bytes per GEMM launch (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included) from "
+                                                 f"rocprofv3 --pmc passes of this very command: {pmc.get('file')}") if pmc else pmc_why,
                                 "algorithmic_bytes_per_launch": pw["gemm_bytes"] / max(1, launches), "avg_launch_us": 1e3 * raw_ms / max(1, launches),
+                                "measured_on": "a second pass over the same row groups right after the timed region: one profiling session "
+                                               "(its own stream, eager launches), HIP events around every GEMM launch on that stream",
                                 "note": "achieved/avg_launch_us use the raw event-pair time (conservative: an empty pair alone "
-                                        "measures event_pair_overhead_us; rocprofv3 kernel-trace averages are in profiles/)",
+                                        "measures event_pair_overhead_us; rocprofv3 kernel-trace averages of the same pass are in profiles/)",
                                 "event_pair_overhead_us": 1e3 * empty_ms,
                                 "avg_launch_us_overhead_removed": 1e3 * net_ms / max(1, launches),
                                 "achieved_overhead_removed": pw["gemm_flops"] / (net_ms * 1e-3) / 1e12,

@@ -319,7 +319,12 @@ struct ttx_session {
   bool tree_big_policy = false;    // TTX_TREE_BIG_POLICY=1: beam paths under the large-row-count GEMM policy too
   int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
   int fuse_ln_min_rows = 0;        // d-wide GEMM + LayerNorm fused (k_gemm_ln256) from this row capacity on; 0: never (slower)
-  int big_min_tiles = 192;         // 128x128 tiling once it yields this many workgroups (k_gemm24); 0: never
+  // k_gemm24 picks the tiling per launch from the live row count (all bit-identical): 128x128 tiles once there are
+  // big_wide_tiles of them, else 128x64 tiles once there are big_min_tiles of THOSE, else 64x64.  Measured per shape in
+  // isolation (tools/bench_gemm.py, gpurun_out/gemm_bench_r2b.log): QKV at 7 936 rows 40.5 -> 35.4 us, FFN1 at 2 480 rows
+  // 39.8 -> 33.8 us under these thresholds; 0 = never a 128-row tiling.
+  int big_min_tiles = 400;
+  int big_wide_tiles = 480;
   int proj_split = 1;              // largest split-K factor of the step's d x d projections on the 64x64 kernel
   int gemm3_max_n = 0;             // step GEMMs at most this wide use the 32x32 kernel (k_gemm3); 0: none
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -410,6 +415,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   if (const char* tb = getenv("TTX_TREE_BIG_POLICY")) s->tree_big_policy = atoi(tb) != 0;
   if (const char* fl = getenv("TTX_FUSE_LN_MIN_ROWS")) s->fuse_ln_min_rows = std::max(0, atoi(fl));
   if (const char* bt = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(bt));
+  if (const char* bw = getenv("TTX_BIG_WIDE_TILES")) s->big_wide_tiles = std::max(0, atoi(bw));
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
@@ -478,6 +484,7 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
   a.slab_stride = slab_stride;
   a.dbg = nullptr;
   a.big_min_tiles = 0;
+  a.big_wide_tiles = s->big_wide_tiles;
   if (s->gemm_debug && s->dbg_gemm.p && (size_t)cdiv(N, 64) * cdiv(Mmax, 64) * S * 64 <= s->dbg_gemm.cap && N == s->gemm_debug_n && !a.raw)
     a.dbg = s->dbg_gemm.as<unsigned long long>();
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -505,7 +512,7 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
       default: hipLaunchKernelGGL((k_gemm3<0>), grid, dim3(256), 0, st, a); break;
     }
   } else if (a.k_per_split % 256 == 0 && !s->gemm_v1 && s->big_min_tiles > 0 &&
-             (long long)cdiv(Mmax, 128) * cdiv(N, 128) * S >= s->big_min_tiles) {
+             (long long)cdiv(Mmax, 128) * cdiv(N, 64) * S >= std::min(s->big_min_tiles, s->big_wide_tiles)) {
     // enough rows (at most) for the 128x128 tiling: one launch that picks the tiling from the live row count
     a.big_min_tiles = s->big_min_tiles;
     dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
@@ -908,7 +915,7 @@ struct GenCtx {
 
 static int launch_accept_and_commit(ttx_session* s, hipStream_t st, const GenCtx& g, bool greedy) {
   if (greedy) hipLaunchKernelGGL(k_greedy_accept, dim3(1), dim3(256), 0, st, g.la);
-  else hipLaunchKernelGGL(k_accept, dim3(1), dim3(256), 0, st, g.la);
+  else hipLaunchKernelGGL(k_accept, dim3(1), dim3(g.k.B > 256 ? ACCEPT_THREADS : 256), 0, st, g.la);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_kvcopy, dim3(g.k.B, s->m->cfg.num_decoder_layers), dim3(256), 0, st, g.kc);
   HIP_TRY(hipGetLastError());
@@ -2383,6 +2390,7 @@ extern "C" int ttx_debug_gemm_bench(ttx_session* s, int M, int N, int K, int spl
   a.X = dx; a.ldx = K; a.W = dw; a.ldw = K; a.bias = db; a.Y = dy; a.ldy = N; a.m_ptr = dm; a.M = M; a.N = N; a.K = K;
   a.relu = 0; a.raw = splits > 0 ? 1 : 0; a.k_per_split = K / S; a.slab_stride = (long long)M * N; a.dbg = nullptr;
   a.big_min_tiles = s->big_min_tiles;
+  a.big_wide_tiles = s->big_wide_tiles;
   if (variant == 24 && (K / S) % 256) return fail(TTX_ERR_INVALID, "variant 24 needs K / splits to be a multiple of 256");
   hipStream_t st = nullptr;
   HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -2393,6 +2401,8 @@ extern "C" int ttx_debug_gemm_bench(ttx_session* s, int M, int N, int K, int spl
       else hipLaunchKernelGGL((k_gemm24<0>), grid, dim3(256), 0, st, g);
     } else if (var == 4) {
       hipLaunchKernelGGL(k_gemm4, dim3(cdiv(N, 128), cdiv(M, 128), S), dim3(256), 0, st, g);
+    } else if (var == 46) {
+      hipLaunchKernelGGL(k_gemm46, dim3(cdiv(N, 64), cdiv(M, 128), S), dim3(256), 0, st, g);
     } else if (var == 3) {
       dim3 grid(cdiv(N, 32), cdiv(M, 32), S);
       switch (g.k_per_split / 4) {

@@ -56,7 +56,8 @@ struct GemmArgs {
   int raw;                   // 1: write un-biased partial sums to slab blockIdx.z
   long long slab_stride;     // floats between slabs
   unsigned long long* dbg;   // diagnostic builds only: per-workgroup phase stamps (100 MHz realtime clock)
-  int big_min_tiles;         // k_gemm24: smallest 128x128-tile count (x splits) at which that tiling is used
+  int big_min_tiles;         // k_gemm24: smallest 128-row-tile count (x splits) at which a 128-row tiling is used
+  int big_wide_tiles;        // k_gemm24: smallest 128x128-tile count at which that tiling is preferred over 128x64
 };
 
 template <int WGM, int WGN>
@@ -342,11 +343,18 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
 // following barrier (loads are unconditional, tile index clamped: counted vmcnt waits).
 struct G4Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
 
+// BN = 128: 2x2 waves of 64x64 (four accumulators per wave).  BN = 64: 2x2 waves of 64x32 (two accumulators per wave, one B
+// fragment): twice the workgroups for the launches that are short of them (N <= 768 at a few thousand rows), so that two
+// are resident per CU and one's prologue / epilogue overlaps the other's MFMAs.  Same K order in one accumulator per
+// element as every other tiling: bit-identical results.
+template <int BN>
 __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const int bx, const int by, const int bz, float* smem) {
-  constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
-  typedef float (*TileBufs)[BM * LDT];
-  TileBufs As = reinterpret_cast<TileBufs>(smem);
-  TileBufs Bs = reinterpret_cast<TileBufs>(smem + 2 * BM * LDT);
+  constexpr int BM = 128, BK = 32, LDT = BK + 4;
+  constexpr int WN = BN / 2;                      // columns per wave
+  typedef float (*TileBufsA)[BM * LDT];
+  typedef float (*TileBufsB)[BN * LDT];
+  TileBufsA As = reinterpret_cast<TileBufsA>(smem);
+  TileBufsB Bs = reinterpret_cast<TileBufsB>(smem + 2 * BM * LDT);
   unsigned long long* dbg = a.dbg ? a.dbg + 8 * (size_t)(bx + gridDim.x * (by + gridDim.y * bz)) : nullptr;
 #ifdef TTX_G4_STAMP_OUTER
   if (dbg && threadIdx.x == 0) dbg[0] = clock64();
@@ -367,7 +375,7 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     xp[i] = a.X + (size_t)min(m0 + lr + 32 * i, M - 1) * a.ldx + kbeg + lc;
-    wp[i] = a.W + (size_t)min(n0 + lr + 32 * i, a.N - 1) * a.ldw + kbeg + lc;
+    wp[i] = a.W + (size_t)min(n0 + min(lr + 32 * i, BN - 1), a.N - 1) * a.ldw + kbeg + lc;
   }
   auto gload = [&](int tile) {
     G4Frag f;
@@ -378,8 +386,10 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     f.a3 = *reinterpret_cast<const float4*>(xp[3] + ko);
     f.b0 = *reinterpret_cast<const float4*>(wp[0] + ko);
     f.b1 = *reinterpret_cast<const float4*>(wp[1] + ko);
-    f.b2 = *reinterpret_cast<const float4*>(wp[2] + ko);
-    f.b3 = *reinterpret_cast<const float4*>(wp[3] + ko);
+    if constexpr (BN == 128) {
+      f.b2 = *reinterpret_cast<const float4*>(wp[2] + ko);
+      f.b3 = *reinterpret_cast<const float4*>(wp[3] + ko);
+    }
     return f;
   };
   auto lstore = [&](const G4Frag& f, int buf) {
@@ -391,14 +401,16 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     *reinterpret_cast<float4*>(as + 96 * LDT) = f.a3;
     *reinterpret_cast<float4*>(bs) = f.b0;
     *reinterpret_cast<float4*>(bs + 32 * LDT) = f.b1;
-    *reinterpret_cast<float4*>(bs + 64 * LDT) = f.b2;
-    *reinterpret_cast<float4*>(bs + 96 * LDT) = f.b3;
+    if constexpr (BN == 128) {
+      *reinterpret_cast<float4*>(bs + 64 * LDT) = f.b2;
+      *reinterpret_cast<float4*>(bs + 96 * LDT) = f.b3;
+    }
   };
 
   f32x16 c00, c01, c10, c11;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; }
-  const int aoff = (wm * 64 + r) * LDT + 4 * h, boff = (wn * 64 + r) * LDT + 4 * h;
+  const int aoff = (wm * 64 + r) * LDT + 4 * h, boff = (wn * WN + r) * LDT + 4 * h;
 #ifdef TTX_G4_PRIO
   // Two workgroups share a CU (one wave of each per SIMD).  With equal priority the SIMD alternates between their
   // MFMAs, both advance in lockstep and reach their LDS/barrier phases together, leaving the MFMA pipe idle then.
@@ -417,31 +429,42 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
       const float4 a0 = *reinterpret_cast<const float4*>(ap + kk);
       const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDT + kk);
       const float4 b0 = *reinterpret_cast<const float4*>(bp + kk);
-      const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDT + kk);
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, c11, 0, 0, 0);
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, c11, 0, 0, 0);
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, c11, 0, 0, 0);
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, c11, 0, 0, 0);
+      if constexpr (BN == 128) {
+        const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDT + kk);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, c11, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, c11, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, c11, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, c11, 0, 0, 0);
+      } else {
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, c10, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
+      }
     }
   };
   // two register tiles in flight (static slots, clamped refills: same shape as k_gemm2's ring): a tile's loads are
   // issued two MFMA blocks (~3.4 us) before its LDS write.  The K range is a multiple of 64: ntiles is even.
   const int last = ntiles - 1;
-  const int bcol = n0 + wn * 64 + r;
+  const int bcol = n0 + wn * WN + r;
   const float bias0 = (!a.raw && a.bias) ? a.bias[min(bcol, a.N - 1)] : 0.f;
-  const float bias1 = (!a.raw && a.bias) ? a.bias[min(bcol + 32, a.N - 1)] : 0.f;
+  const float bias1 = (!a.raw && a.bias && BN == 128) ? a.bias[min(bcol + 32, a.N - 1)] : 0.f;
   asm volatile("" ::: "memory");
   G4Frag f0 = gload(0);
   asm volatile("" ::: "memory");        // issue order f0 then f1 also ahead of the loop: the header waits with vmcnt(8), not 0
@@ -483,7 +506,7 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
   float* Y = a.Y + (a.raw ? (size_t)bz * a.slab_stride : 0);
   const float lo = a.relu ? 0.f : -INFINITY;
   auto store_tile = [&](const f32x16& c, int tm, int tn, float bv) {
-    const int col = n0 + wn * 64 + tn * 32 + r;
+    const int col = n0 + wn * WN + tn * 32 + r;
     float val[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) val[v] = fmaxf(c[v] + bv, lo);
@@ -502,9 +525,9 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     }
   };
   store_tile(c00, 0, 0, bias0);
-  store_tile(c01, 0, 1, bias1);
+  if constexpr (BN == 128) store_tile(c01, 0, 1, bias1);
   store_tile(c10, 1, 0, bias0);
-  store_tile(c11, 1, 1, bias1);
+  if constexpr (BN == 128) store_tile(c11, 1, 1, bias1);
 #ifdef TTX_G4_STAMP_OUTER
   if (dbg && t == 0) {
     dbg[4] = clock64();
@@ -518,7 +541,14 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
 __global__ __launch_bounds__(256) void k_gemm4(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[G24_SMEM_FLOATS];
   const int M = a.m_ptr ? *a.m_ptr : a.M;
-  g4_body(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  g4_body<128>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// 128x64 tiles in isolation (tools/bench_gemm.py variant 46).
+__global__ __launch_bounds__(256) void k_gemm46(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[G24_SMEM_FLOATS];
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  g4_body<64>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // One launch, two tilings: the grid is laid out for 64x64 tiles; when the row count read from the device gives the
@@ -530,24 +560,31 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_gemm24(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[G24_SMEM_FLOATS];
   const int M = a.m_ptr ? *a.m_ptr : a.M;
-  const int big_tiles = ((M + 127) >> 7) * ((a.N + 127) >> 7) * (int)gridDim.z;
-  if (big_tiles >= a.big_min_tiles) {
-    // The first big_tiles workgroups of the whole grid in dispatch order take the tiles (all K slices included): the
-    // dispatcher hands consecutive workgroups to consecutive CUs, so a contiguous block spreads one per CU / XCD;
-    // actives separated by idle workgroups ended up two to a CU with other CUs empty (2x the time, measured).
-    const int nbx = (a.N + 127) >> 7, nby = (M + 127) >> 7;
+  const int nby = (M + 127) >> 7;
+  const int big_tiles = nby * ((a.N + 127) >> 7) * (int)gridDim.z;
+  const int mid_tiles = nby * ((a.N + 63) >> 6) * (int)gridDim.z;         // 128x64 tiles
+  // 128x128 tiles when they fill the chip about twice over (big_wide_tiles), else 128x64 tiles when THOSE reach
+  // big_min_tiles, else 64x64.  All three accumulate a K range in the same order: bit-identical results.
+  const bool wide = big_tiles >= a.big_wide_tiles;
+  if (wide || mid_tiles >= a.big_min_tiles) {
+    // The first tiles of the whole grid in dispatch order take the work (all K slices included): the dispatcher hands
+    // consecutive workgroups to consecutive CUs, so a contiguous block spreads one per CU / XCD; actives separated by idle
+    // workgroups ended up two to a CU with other CUs empty (2x the time, measured).
+    const int n_tiles = wide ? big_tiles : mid_tiles;
+    const int nbx = wide ? (a.N + 127) >> 7 : (a.N + 63) >> 6;
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (lin >= big_tiles) return;
+    if (lin >= n_tiles) return;
 #ifndef TTX_NO_XCD_REMAP
     // XCD-aware order (speed only): workgroups lin and lin + 8 share an XCD and its L2, so the workgroups of one XCD
     // take a CONTIGUOUS run of tiles — the column tiles of a row block (same X rows) then hit one L2 instead of eight.
-    const int xb = big_tiles >> 3, xr = big_tiles & 7, xcd = lin & 7;
+    const int xb = n_tiles >> 3, xr = n_tiles & 7, xcd = lin & 7;
     const int v = xcd * xb + min(xcd, xr) + (lin >> 3);
 #else
     const int v = lin;
 #endif
     const int slice = v / (nbx * nby), rem = v - slice * (nbx * nby);
-    g4_body(a, M, rem % nbx, rem / nbx, slice, smem);
+    if (wide) g4_body<128>(a, M, rem % nbx, rem / nbx, slice, smem);
+    else g4_body<64>(a, M, rem % nbx, rem / nbx, slice, smem);
   } else {
     g2_body<NT>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
   }
@@ -1842,11 +1879,12 @@ __global__ void k_loop_init(LoopArgs a) {
 
 // One block.  Verify each draft against the argmax tokens, keep the longest accepted prefix plus one
 // bonus token, retire rows that produced EOS, compact the active list, decide whether the loop goes on.
-__global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
+constexpr int ACCEPT_THREADS = 1024;                // one slot per thread up to 1 024 slots per round; 16 waves copy finished rows
+__global__ __launch_bounds__(ACCEPT_THREADS) void k_accept(LoopArgs a) {
   __shared__ int s_maxfront, s_anyfin, s_suspect, s_nn, s_maxf_new, s_nfin;
   __shared__ int s_finlist[256];                    // finished rows of this step (their output copy is shared out below)
   __shared__ long long s_acc, s_prefix;
-  __shared__ int s_scan[256];
+  __shared__ int s_scan[ACCEPT_THREADS];
   DecState* st = a.st;
   const int Bc = st->n_active;
   if (Bc == 0) return;
@@ -1938,7 +1976,7 @@ __global__ __launch_bounds__(256) void k_accept(LoopArgs a) {
     for (int c = first; c < wout; c += stride) orow[c] = g[c];
   };
   if (s_nfin <= 256) {                               // one wave per finished row
-    for (int k = threadIdx.x >> 6; k < s_nfin; k += 4) copy_row(s_finlist[k], threadIdx.x & 63, 64);
+    for (int k = threadIdx.x >> 6; k < s_nfin; k += (int)(blockDim.x >> 6)) copy_row(s_finlist[k], threadIdx.x & 63, 64);
   } else {                                           // more rows finished at once than the list holds: scan all slots
     for (int slot = 0; slot < Bc; ++slot)
       if (a.rec[slot].flags == 1) copy_row(a.rec[slot].b, threadIdx.x, blockDim.x);
