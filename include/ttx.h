@@ -142,24 +142,6 @@ int ttx_greedy_speculative_generate(ttx_session* s, const int64_t* d_src, int B,
 int ttx_greedy_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_gen_params* p,
                         int64_t* d_out, ttx_gen_stats* stats, void* stream);
 
-/* Tree (beam) decoding with a per-candidate KV cache — the decoder side of TranslationInferenceBeamSearch
- * (src/decoding/standard_decoding.py:89-174) and TranslationInferenceBeamSearchSpeculative
- * (src/decoding/speculative_decoding.py:428-845), which call decode_tgt on (candidate x draft) rows every
- * iteration (:518, :747, standard_decoding.py:138).  ttx_tree_begin encodes the sources and projects the
- * cross-attention K/V once; every ttx_tree_step decodes, for each active candidate, its last token plus N
- * drafts of D tokens on top of the candidate's cached prefix and returns the logits of those D+1 positions
- * per draft.  A candidate's cache is derived from its parent's: parent = index of the candidate of the
- * PREVIOUS step it extends (-1: a fresh <BOS> row), parent_draft = the parent's draft slot whose first
- * len - parent_len - 1 tokens were kept.
- *   d_cand int64 [n_cand,width] left-aligned tokens (PAD after);  d_len int32 [n_cand] real tokens per row;
- *   d_src_row int32 [n_cand] source row of each candidate;  d_active uint8 [n_cand] (0: skipped, e.g. finished);
- *   d_drafts int64 [n_cand,N,D];  d_logits fp32 [n_cand,N,D+1,V] out (rows of inactive candidates untouched). */
-int ttx_tree_begin(ttx_session* s, const int64_t* d_src, int B, int Ls, int max_cand, int max_len, int n_drafts,
-                   int draft_len, void* stream);
-int ttx_tree_step(ttx_session* s, const int64_t* d_cand, int n_cand, int width, const int32_t* d_len,
-                  const int32_t* d_parent, const int32_t* d_parent_draft, const int32_t* d_src_row,
-                  const uint8_t* d_active, const int64_t* d_drafts, int N, int D, float* d_logits, void* stream);
-
 /* Beam-speculative bookkeeping kernels.
  * ttx_nucleus_mask: mask_with_num_logits_according_nucleus (src/decoding/speculative_decoding.py:871-904): per row of
  *   d_logits [rows,V] keep the best logit and further ones, best first, while the softmax mass ranked above is
@@ -219,6 +201,25 @@ int ttx_beam_speculative_generate(ttx_session* s, const int64_t* d_src, int B, i
 int ttx_beam_speculative_generate_many(ttx_session** sessions, int n_sessions, int n_batches, const int64_t* const* d_src,
                                        const int* B, const int* Ls, const ttx_beam_params* p, int64_t* const* d_out,
                                        ttx_beam_stats* stats, void* stream);
+
+/* TranslationInferenceBeamSearch.generate (src/decoding/standard_decoding.py:89-174) — the whole loop on the device with a
+ * per-hypothesis KV cache: the <BOS> step (:102), then up to max_len - 2 iterations of {decoder on the unfinished hypotheses,
+ * artificial "35 on PAD" logits for the finished ones (:133-135), log(softmax) + running score, topk(beam) over beam x V per
+ * source (:151-153), row assembly (:154-161)}, ending early once every hypothesis holds EOS (:166).
+ *   d_src int64 [B, Ls];  d_out int64 [B, beam_size, max_len] (row stride max_len): the reference's result [B, beam, W]
+ *   occupies the first W = stats->out_width columns, hypotheses best first. */
+typedef struct ttx_beam_search_params {
+  int32_t max_len, beam_size;
+  int32_t pad_token, bos_token, eos_token;
+} ttx_beam_search_params;
+typedef struct ttx_beam_search_stats {
+  int64_t model_calls;     /* generator.model_calls_num                                              */
+  int64_t running_rows;    /* generator.b_sz: decoder rows over all calls (unfinished hypotheses)    */
+  int32_t out_width;
+  int32_t pad_;
+} ttx_beam_search_stats;
+int ttx_beam_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_beam_search_params* p, int64_t* d_out,
+                      ttx_beam_search_stats* stats, void* stream);
 
 /* Several batches in flight on one GPU (the scheduling SURVEY.md §8(f) #1 names; the reference's predict loop
  * is strictly one batch at a time, src/model/lightning_model.py:209-212).  Batch i is decoded on

@@ -61,6 +61,15 @@ class BeamStats(C.Structure):
                 ("out_width", C.c_int32), ("status", C.c_int32)]
 
 
+class BeamSearchParams(C.Structure):
+    _fields_ = [("max_len", C.c_int32), ("beam_size", C.c_int32), ("pad_token", C.c_int32), ("bos_token", C.c_int32),
+                ("eos_token", C.c_int32)]
+
+
+class BeamSearchStats(C.Structure):
+    _fields_ = [("model_calls", C.c_int64), ("running_rows", C.c_int64), ("out_width", C.c_int32), ("pad_", C.c_int32)]
+
+
 class GenStats(C.Structure):
     _fields_ = [("model_calls", C.c_int64), ("accepted_tokens", C.c_int64), ("produced_tokens", C.c_int64),
                 ("verified_positions", C.c_int64), ("kv_prefix_positions", C.c_int64), ("src_positions", C.c_int64),
@@ -98,11 +107,10 @@ SYMBOLS = {
     "ttx_beam_speculative_generate_many": (C.c_int, [C.POINTER(_VP), _I, _I, C.POINTER(_VP), C.POINTER(C.c_int),
                                                     C.POINTER(C.c_int), C.POINTER(BeamParams), C.POINTER(_VP),
                                                     C.POINTER(BeamStats), _VP]),
+    "ttx_beam_generate": (C.c_int, [_VP, _VP, _I, _I, C.POINTER(BeamSearchParams), _VP, C.POINTER(BeamSearchStats), _VP]),
     "ttx_nucleus_mask": (C.c_int, [_VP, _VP, _I, _I, C.c_float, _I, C.c_float, _VP, _VP]),
     "ttx_accepted_lengths": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _I, _VP, _VP]),
     "ttx_ragged_topk": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
-    "ttx_tree_begin": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
-    "ttx_tree_step": (C.c_int, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "ttx_tokenizer_create": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), _I, C.POINTER(_VP)]),
     "ttx_tokenizer_destroy": (None, [_VP]),
     "ttx_tokenizer_encode": (C.c_int, [_VP, C.c_char_p, _VP, _I]),

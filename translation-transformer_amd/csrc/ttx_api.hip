@@ -282,8 +282,7 @@ struct ttx_session {
       bs_chosen, bs_parent, bs_parent_draft, bs_mark, bs_drafts_src, bs_cnt;
   BeamHost* beam_host = nullptr;   // pinned + device-mapped, written by k_bs_publish
   // tree (beam) decoding
-  Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of, t_len, t_parent, t_parent_draft, t_active;
-  struct { int B = 0, Ls = 0, max_cand = 0, max_len = 0, N = 0, D = 0, Lc = 0, gen_ld = 0, cur = 0, prev_N = 1, prev_D = 0, steps = 0; } tree;
+  Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of;
   bool attn_debug = false;
   bool gemm_debug = false;
   int gemm_debug_n = 0;
@@ -340,7 +339,7 @@ struct ttx_session {
                                  &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
                                  &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &traj, &fin_step, &rstep, &row_of, &src_len, &new_slot,
                                  &pool_io, &memkv_new, &valid_new, &drafts_new, &tk[0], &tk[1], &tv[0], &tv[1],
-                                 &t_prev_len, &t_slot_of, &t_src_of, &t_len, &t_parent, &t_parent_draft, &t_active, &dbg_gemm,
+                                 &t_prev_len, &t_slot_of, &t_src_of, &dbg_gemm,
                                  &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state, &leaf_score, &leaf_tok, &leaf_cnt,
                                  &beam_summary, &bs_cand_next, &bs_len_next, &bs_fin_next, &bs_logp_next, &bs_len, &bs_fin, &bs_active,
                                  &bs_logp, &bs_per_cand, &bs_best_n, &bs_best_slot, &bs_chosen, &bs_parent, &bs_parent_draft, &bs_mark,
@@ -1708,113 +1707,6 @@ extern "C" int ttx_greedy_speculative_generate_rows(ttx_session** sessions, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tree (beam) decoding: encoder + cross K/V once (begin), then one KV-cached verify step per call.
-extern "C" int ttx_tree_begin(ttx_session* s, const int64_t* d_src, int B, int Ls, int max_cand, int max_len, int n_drafts,
-                              int draft_len, void* stream) {
-  if (!s || !d_src || B <= 0 || Ls <= 1 || max_cand < B || max_len < 1 || n_drafts < 1 || draft_len < 0)
-    return fail(TTX_ERR_INVALID, "bad argument to ttx_tree_begin");
-  const ttx_model* m = s->m;
-  const ttx_config& c = m->cfg;
-  if (max_len + draft_len + 2 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len + draft_len exceeds the positional table");
-  HIP_TRY(hipSetDevice(m->device));
-  release_retired();
-  hipStream_t st = (hipStream_t)stream;
-  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
-  auto& t = s->tree;
-  t.B = B; t.Ls = Ls; t.max_cand = max_cand; t.max_len = max_len; t.N = n_drafts; t.D = draft_len;
-  t.Lc = max_len + draft_len + 2; t.gen_ld = max_len + draft_len + 2; t.cur = 0; t.prev_N = 1; t.prev_D = 0; t.steps = 0;
-  const size_t Mmax = (size_t)max_cand * step_rps(n_drafts, draft_len);
-  int rc = TTX_OK;
-  auto need = [&](Buf& b, size_t bytes) { if (rc == TTX_OK) rc = ensure(b, bytes, st); };
-  need(s->tok_src, (size_t)B * Ls * 4); need(s->src_valid, (size_t)B * Ls); need(s->memory, (size_t)B * Ls * d * 4);
-  need(s->memkv, (size_t)B * Ls * Ld * 2 * d * 4);
-  need(s->drafts, (size_t)max_cand * n_drafts * std::max(draft_len, 1) * 4);
-  need(s->gen, (size_t)max_cand * t.gen_ld * 4); need(s->front, (size_t)max_cand * 4); need(s->act_idx, (size_t)max_cand * 4);
-  need(s->pred, Mmax * 4); need(s->state, sizeof(DecState)); need(s->logits, Mmax * V * 4);
-  for (int i = 0; i < 2; ++i) { need(s->tk[i], (size_t)Ld * max_cand * t.Lc * d * 4); need(s->tv[i], (size_t)Ld * max_cand * t.Lc * d * 4); }
-  need(s->t_prev_len, (size_t)max_cand * 4); need(s->t_slot_of, (size_t)max_cand * 4); need(s->t_src_of, (size_t)max_cand * 4);
-  need(s->t_len, (size_t)max_cand * 4); need(s->t_parent, (size_t)max_cand * 4); need(s->t_parent_draft, (size_t)max_cand * 4);
-  need(s->t_active, (size_t)max_cand);
-  const size_t Macts = std::max(Mmax, (size_t)B * Ls);
-  if (rc == TTX_OK) rc = ensure_acts(s, st, Macts, 1);
-  need(s->qkv, std::max((size_t)Ld * Mmax, (size_t)B * Ls) * 3 * d * 4);
-  need(s->slab, sizeof(float) * 16 * Macts * d);
-  s->graphs_current();
-  TTX_TRY(rc);
-  TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
-  TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));
-  return launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv.as<float>(),
-                     Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0);
-}
-
-extern "C" int ttx_tree_step(ttx_session* s, const int64_t* d_cand, int n_cand, int width, const int32_t* d_len,
-                             const int32_t* d_parent, const int32_t* d_parent_draft, const int32_t* d_src_row,
-                             const uint8_t* d_active, const int64_t* d_drafts, int N, int D, float* d_logits, void* stream) {
-  if (!s || !d_cand || !d_len || !d_parent || !d_parent_draft || !d_src_row || !d_active || !d_logits || (!d_drafts && D > 0))
-    return fail(TTX_ERR_INVALID, "null argument to ttx_tree_step");
-  auto& t = s->tree;
-  if (t.B <= 0) return fail(TTX_ERR_INVALID, "ttx_tree_step before ttx_tree_begin");
-  if (n_cand <= 0 || n_cand > t.max_cand || N < 1 || N > t.N || D < 0 || D > t.D || width < 1 || width > t.gen_ld)
-    return fail(TTX_ERR_INVALID, "ttx_tree_step: shape outside what ttx_tree_begin sized");
-  const ttx_model* m = s->m;
-  const ttx_config& c = m->cfg;
-  HIP_TRY(hipSetDevice(m->device));
-  hipStream_t st = (hipStream_t)stream;
-  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
-  const long long cache_seq = (long long)t.Lc * d, cache_layer = (long long)t.max_cand * cache_seq;
-  const int nxt = t.cur ^ 1;
-  // 1. every candidate's cache = its parent's cache + the parent's accepted rows of the previous step
-  if (t.steps > 0) {
-    TreeCacheArgs ca{};
-    ca.len = d_len; ca.parent = d_parent; ca.parent_draft = d_parent_draft; ca.prev_len = s->t_prev_len.as<int>(); ca.active = d_active;
-    ca.k_old = s->tk[t.cur].as<float>(); ca.v_old = s->tv[t.cur].as<float>();
-    ca.k_new = s->tk[nxt].as<float>(); ca.v_new = s->tv[nxt].as<float>();
-    ca.cache_layer_stride = cache_layer; ca.cache_seq_stride = cache_seq;
-    ca.qkv_prev = s->qkv.as<float>();
-    ca.qkv_layer_stride = (long long)t.max_cand * step_rps(t.prev_N, t.prev_D) * 3 * d;   // run_step's layout of the previous call
-    ca.prev_slot_of = s->t_slot_of.as<int>(); ca.prev_N = t.prev_N; ca.prev_D = t.prev_D; ca.d = d;
-    hipLaunchKernelGGL(k_tree_cache, dim3(n_cand, Ld), dim3(256), 0, st, ca);
-    HIP_TRY(hipGetLastError());
-  }
-  t.cur = nxt;
-  // 2. loop state for the verify-step kernels
-  TreePrepArgs pa{};
-  pa.cand = d_cand; pa.width = width; pa.len = d_len; pa.active = d_active; pa.drafts = d_drafts;
-  pa.n_cand = n_cand; pa.N = N; pa.D = D; pa.pad = c.pad_token;
-  pa.gen = s->gen.as<int>(); pa.gen_ld = t.gen_ld; pa.front = s->front.as<int>(); pa.act_idx = s->act_idx.as<int>();
-  pa.drafts32 = s->drafts.as<int>(); pa.st = s->state.as<DecState>();
-  hipLaunchKernelGGL(k_tree_prep, dim3(std::min(64, cdiv(n_cand * t.gen_ld, 256))), dim3(256), 0, st, pa);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_tree_slots, dim3(1), dim3(256), 0, st, s->state.as<DecState>(), s->act_idx.as<int>(), s->t_slot_of.as<int>(),
-                     d_len, s->t_prev_len.as<int>(), n_cand);
-  HIP_TRY(hipGetLastError());
-  // 3. the verify step itself (embed, Ld decoder layers on the KV cache, classifier)
-  StepCtx k{};
-  k.B = t.max_cand; k.Ls = t.Ls; k.N = N; k.D = D; k.Lc = t.Lc; k.gen_ld = t.gen_ld; k.max_len = t.max_len;
-  k.kcache = s->tk[t.cur].as<float>(); k.vcache = s->tv[t.cur].as<float>(); k.src_of = d_src_row; k.want_argmax = false;
-  // NOTE: the step kernels lay their rows out with stride max_cand * RPS(N, D) per layer in s->qkv
-  {
-    // The beam paths verify a few hundred rows per step: they run under the small-batch kernel policy (32x32 K-split
-    // kernel for the narrow GEMMs, deeper split-K — §4.2 of DESIGN.md).  The greedy paths keep one policy for every
-    // row count so that their outputs are bit-identical across groupings; the beam paths never mix with them.
-    struct PolicyScope {
-      ttx_session* s; int g3, ps, fs, bt;
-      explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles) {
-        if (!s->tree_big_policy) { s->gemm3_max_n = 768; s->proj_split = 4; s->ffn2_split = 8; s->big_min_tiles = 0; }
-      }
-      ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; }
-    } scope(s);
-    TTX_TRY(run_step(s, st, k, std::min(t.max_len, ((width + 63) / 64) * 64)));
-  }
-  // 4. logits of the step rows -> [n_cand, N, D+1, V]
-  hipLaunchKernelGGL(k_tree_logits, dim3(n_cand, N * (D + 1)), dim3(256), 0, st, s->logits.as<float>(), V, s->state.as<DecState>(),
-                     s->act_idx.as<int>(), N, D, d_logits);
-  HIP_TRY(hipGetLastError());
-  t.prev_N = N; t.prev_D = D; t.steps += 1;
-  return TTX_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
 // Beam-speculative bookkeeping
 extern "C" int ttx_nucleus_mask(ttx_session* s, const float* d_logits, int rows, int V, float nucleus, int n_best, float fill,
                                 float* d_out, void* stream) {
@@ -2263,6 +2155,161 @@ extern "C" int ttx_beam_speculative_generate(ttx_session* s, const int64_t* d_sr
   if (!s) return fail(TTX_ERR_INVALID, "null session");
   const int rc = ttx_beam_speculative_generate_many(ss, 1, 1, srcs, &B, &Ls, p, outs, stats ? stats : &local, stream);
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Standard beam search, whole loop native (standard_decoding.py:89-174): per-hypothesis KV cache (the tree kernels),
+// the verify-step kernels with one row per running hypothesis, k_beam_step for log-softmax + top-beam + row assembly.
+extern "C" int ttx_beam_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_beam_search_params* p, int64_t* d_out,
+                                 ttx_beam_search_stats* stats, void* stream) {
+  if (!s || !d_src || !p || !d_out || !stats || B <= 0 || Ls <= 1) return fail(TTX_ERR_INVALID, "bad argument to ttx_beam_generate");
+  TTX_TRY(session_alive(s));
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const int K = p->beam_size, max_len = p->max_len, V = c.vocab_size;
+  if (max_len <= 1) return fail(TTX_ERR_REFERENCE, "assert self.max_len > 1 (standard_decoding.py:79)");
+  if (K <= 0) return fail(TTX_ERR_REFERENCE, "assert self.beam_size > 0 (standard_decoding.py:80)");
+  if (K > V) return fail(TTX_ERR_REFERENCE, "beam_size larger than the vocabulary: topk(k) of the first step raises");
+  if ((size_t)K * V * 4 > 150 * 1024) return fail(TTX_ERR_INVALID, "beam_size x vocabulary beyond the selection kernel's LDS image");
+  if (p->pad_token != c.pad_token) return fail(TTX_ERR_INVALID, "generator pad token differs from the model's");
+  if (max_len + 2 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len exceeds the positional table");
+  HIP_TRY(hipSetDevice(m->device));
+  release_retired();
+  if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventRecord(s->ev_done, (hipStream_t)stream));
+  HIP_TRY(hipStreamWaitEvent(s->own_stream, s->ev_done, 0));
+  hipStream_t st = s->own_stream;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers;
+  const int MC = B * K, ld = max_len + 2, Lc = max_len + 2;
+  const size_t Mmax = (size_t)MC;
+  int rc = TTX_OK;
+  auto need = [&](Buf& b, size_t bytes) { if (rc == TTX_OK) rc = ensure(b, bytes, st); };
+  need(s->tok_src, (size_t)B * Ls * 4); need(s->src_valid, (size_t)B * Ls); need(s->memory, (size_t)B * Ls * d * 4);
+  need(s->memkv, (size_t)B * Ls * Ld * 2 * d * 4);
+  need(s->drafts, (size_t)MC * 4);
+  need(s->gen, (size_t)MC * ld * 4); need(s->front, (size_t)MC * 4); need(s->act_idx, (size_t)MC * 4);
+  need(s->pred, Mmax * 4); need(s->state, sizeof(DecState)); need(s->logits, Mmax * V * 4);
+  for (int i = 0; i < 2; ++i) { need(s->tk[i], (size_t)Ld * MC * Lc * d * 4); need(s->tv[i], (size_t)Ld * MC * Lc * d * 4); }
+  need(s->t_prev_len, (size_t)MC * 4); need(s->t_slot_of, (size_t)MC * 4); need(s->t_src_of, (size_t)MC * 4);
+  need(s->bs_cand_next, (size_t)MC * ld * 8); need(s->bs_len_next, (size_t)MC * 4); need(s->bs_fin_next, (size_t)MC);
+  need(s->bs_logp_next, (size_t)MC * 4); need(s->bs_len, (size_t)MC * 4); need(s->bs_fin, (size_t)MC); need(s->bs_active, (size_t)MC);
+  need(s->bs_logp, (size_t)MC * 4); need(s->bs_per_cand, (size_t)MC * 4); need(s->bs_parent, (size_t)MC * 4);
+  need(s->bs_parent_draft, (size_t)MC * 4); need(s->bs_cnt, sizeof(BeamCounters)); need(s->beam_summary, 8 * 4);
+  const size_t Macts = std::max(Mmax, (size_t)B * Ls);
+  if (rc == TTX_OK) rc = ensure_acts(s, st, Macts, 1);
+  need(s->qkv, std::max((size_t)Ld * Mmax, (size_t)B * Ls) * 3 * d * 4);
+  need(s->slab, sizeof(float) * 16 * Macts * d);
+  s->graphs_current();
+  TTX_TRY(rc);
+  if (!s->beam_host && hipHostMalloc((void**)&s->beam_host, sizeof(BeamHost), hipHostMallocMapped) != hipSuccess)
+    return fail(TTX_ERR_NOMEM, "hipHostMalloc failed");
+  std::memset(s->beam_host, 0, sizeof(BeamHost));
+  BeamHost* dev_host = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&dev_host, (void*)s->beam_host, 0));
+  // self.model(src, y) of the first step = encoder + the decoder on <BOS>; the reference then re-encodes the source once per
+  // beam (:120-124): identical rows, so the beams of a source share its memory row here
+  TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
+  TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));
+  TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv.as<float>(),
+                      Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0));
+  hipLaunchKernelGGL(k_bs_init, dim3(64), dim3(256), 0, st, s->bs_cand_next.as<int64_t>(), ld, s->bs_len_next.as<int>(),
+                     s->bs_fin_next.as<uint8_t>(), s->bs_logp_next.as<float>(), s->bs_parent.as<int>(), s->bs_parent_draft.as<int>(),
+                     MC, B, p->bos_token, p->pad_token, s->bs_cnt.as<BeamCounters>());
+  HIP_TRY(hipGetLastError());
+
+  const long long cache_seq = (long long)Lc * d, cache_layer = (long long)MC * cache_seq;
+  int n_cand = B, beam = 1, width = 1, cur = 0, launched = 0;
+  const int max_iters = max_len - 1;                 // the <BOS> step plus `predictions - 1` loop iterations (:127-131)
+  auto enqueue = [&](bool first) -> int {
+    BeamPrepArgs pa{};
+    pa.cand_next = s->bs_cand_next.as<int64_t>(); pa.ld = ld; pa.len_next = s->bs_len_next.as<int>();
+    pa.fin_next = s->bs_fin_next.as<uint8_t>(); pa.logp_next = s->bs_logp_next.as<float>();
+    pa.n_cand = n_cand; pa.beam = beam; pa.dl = 0; pa.N = 1; pa.pad = p->pad_token; pa.smart = 0;
+    pa.gen = s->gen.as<int>(); pa.front = s->front.as<int>(); pa.len = s->bs_len.as<int>(); pa.active = s->bs_active.as<uint8_t>();
+    pa.finished = s->bs_fin.as<uint8_t>(); pa.logp = s->bs_logp.as<float>(); pa.per_cand = s->bs_per_cand.as<int>();
+    pa.drafts32 = s->drafts.as<int>();
+    hipLaunchKernelGGL(k_bs_prep, dim3(MC), dim3(256), 0, st, pa);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_bs_src_of, dim3(cdiv(MC, 256)), dim3(256), 0, st, s->t_src_of.as<int>(), MC, beam);
+    HIP_TRY(hipGetLastError());
+    const int nxt = cur ^ 1;
+    if (!first) {
+      TreeCacheArgs ca{};
+      ca.len = s->bs_len.as<int>(); ca.parent = s->bs_parent.as<int>(); ca.parent_draft = s->bs_parent_draft.as<int>();
+      ca.prev_len = s->t_prev_len.as<int>(); ca.active = s->bs_active.as<uint8_t>();
+      ca.k_old = s->tk[cur].as<float>(); ca.v_old = s->tv[cur].as<float>(); ca.k_new = s->tk[nxt].as<float>(); ca.v_new = s->tv[nxt].as<float>();
+      ca.cache_layer_stride = cache_layer; ca.cache_seq_stride = cache_seq;
+      ca.qkv_prev = s->qkv.as<float>(); ca.qkv_layer_stride = (long long)MC * 3 * d;
+      ca.prev_slot_of = s->t_slot_of.as<int>(); ca.prev_N = 1; ca.prev_D = 0; ca.d = d;
+      hipLaunchKernelGGL(k_tree_cache, dim3(MC, Ld), dim3(256), 0, st, ca);
+      HIP_TRY(hipGetLastError());
+    }
+    BeamListArgs la{};
+    la.active = s->bs_active.as<uint8_t>(); la.per_cand = s->bs_per_cand.as<int>(); la.len = s->bs_len.as<int>();
+    la.n_cand = n_cand; la.N = 1; la.dl = 0;
+    la.act_idx = s->act_idx.as<int>(); la.slot_of = s->t_slot_of.as<int>(); la.prev_len = s->t_prev_len.as<int>();
+    la.st = s->state.as<DecState>(); la.cnt = s->bs_cnt.as<BeamCounters>(); la.summary = s->beam_summary.as<int>();
+    hipLaunchKernelGGL(k_bs_list, dim3(1), dim3(256), 0, st, la);
+    HIP_TRY(hipGetLastError());
+    StepCtx k{};
+    k.B = MC; k.Ls = Ls; k.N = 1; k.D = 0; k.Lc = Lc; k.gen_ld = ld; k.max_len = max_len;
+    k.kcache = s->tk[nxt].as<float>(); k.vcache = s->tv[nxt].as<float>(); k.src_of = s->t_src_of.as<int>(); k.want_argmax = false;
+    {
+      struct PolicyScope {
+        ttx_session* s; int g3, ps, fs, bt;
+        explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles) {
+          if (!s->tree_big_policy) { s->gemm3_max_n = 768; s->proj_split = 4; s->ffn2_split = 8; s->big_min_tiles = 0; }
+        }
+        ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; }
+      } scope(s);
+      TTX_TRY(run_step(s, st, k, std::min(max_len, ((width + 63) / 64) * 64)));
+    }
+    BeamStepArgs sa{};
+    sa.logits = s->logits.as<float>(); sa.V = V; sa.slot_of = s->t_slot_of.as<int>(); sa.finished = s->bs_fin.as<uint8_t>();
+    sa.score = s->bs_logp.as<float>(); sa.gen = s->gen.as<int>(); sa.ld = ld; sa.width = width;
+    sa.B = B; sa.beam = beam; sa.K = K; sa.pad = p->pad_token; sa.eos = p->eos_token;
+    sa.new_cand = s->bs_cand_next.as<int64_t>(); sa.new_score = s->bs_logp_next.as<float>(); sa.parent = s->bs_parent.as<int>();
+    sa.new_len = s->bs_len_next.as<int>(); sa.new_finished = s->bs_fin_next.as<uint8_t>(); sa.parent_draft = s->bs_parent_draft.as<int>();
+    sa.summary = s->beam_summary.as<int>();
+    const size_t lds = (size_t)beam * V * 4;
+    static bool attr = false;
+    if (lds > 64 * 1024 && !attr) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_beam_step), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL(k_beam_step, dim3(B), dim3(256), lds, st, sa);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_bs_publish, dim3(1), dim3(64), 0, st, s->beam_summary.as<int>(), dev_host, s->bs_cnt.as<BeamCounters>());
+    HIP_TRY(hipGetLastError());
+    return TTX_OK;
+  };
+  volatile BeamHost* bh = s->beam_host;
+  while (launched < max_iters) {
+    const bool first = launched == 0;
+    // width changes every step, so a step's graph would be replayed once: the steps run eagerly (about 12 launches per
+    // decoder layer, enqueued well ahead of the device)
+    TTX_TRY(enqueue(first));
+    ++launched;
+    cur ^= 1;
+    unsigned spins = 0;
+    const auto since = std::chrono::steady_clock::now();
+    while (bh->steps_done < launched) {
+      if ((++spins & 0xffff) == 0 && watchdog_expired(since)) return session_hung(s);
+      __builtin_ia32_pause();
+    }
+    width += 1;
+    n_cand = B * K; beam = K;
+    if (bh->summary[0] == B * K && !first) break;                   // :166 (the check sits inside the loop, after the first step)
+  }
+  HIP_TRY(hipMemcpy2DAsync(d_out, (size_t)max_len * 8, s->bs_cand_next.p, (size_t)ld * 8, (size_t)width * 8, (size_t)B * K,
+                           hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->host_state, s->bs_cnt.p, sizeof(BeamCounters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const BeamCounters* cn = reinterpret_cast<const BeamCounters*>(s->host_state);
+  stats->model_calls = cn->model_calls;
+  stats->running_rows = cn->running_cands;
+  stats->out_width = width;
+  return TTX_OK;
 }
 
 // Parity instrumentation: the verify step selected by ttx_gen_params.want_logits (1-based step number) of the most

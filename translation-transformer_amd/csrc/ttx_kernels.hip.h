@@ -2511,35 +2511,6 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
 // Tree (beam) decoding with a per-candidate KV cache: SURVEY.md §2.3 K12-K14's decoder side.  A "candidate" is one
 // hypothesis row (n_best per source); its cache is rebuilt every step from its parent's cache plus the parent's
 // accepted step rows, then the same verify-step kernels run with candidate = running row.
-struct TreePrepArgs {
-  const int64_t* cand; int width;        // [n_cand, width] tokens, left-aligned, PAD after
-  const int* len;                        // [n_cand] real tokens per candidate (last one = front)
-  const uint8_t* active;                 // [n_cand]
-  const int64_t* drafts;                 // [n_cand, N, D]
-  int n_cand, N, D, pad;
-  int* gen; int gen_ld; int* front; int* act_idx; int* drafts32; DecState* st;
-};
-
-__global__ __launch_bounds__(256) void k_tree_prep(TreePrepArgs a) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-  for (int i = tid; i < a.n_cand * a.gen_ld; i += nth) {
-    const int c = i / a.gen_ld, col = i % a.gen_ld;
-    a.gen[i] = col < a.width ? (int)a.cand[(size_t)c * a.width + col] : a.pad;
-  }
-  for (int i = tid; i < a.n_cand * a.N * a.D; i += nth) a.drafts32[i] = (int)a.drafts[i];
-  for (int i = tid; i < a.n_cand; i += nth) a.front[i] = a.len[i] - 1;
-  if (tid == 0) {
-    int n = 0;
-    for (int c = 0; c < a.n_cand; ++c)
-      if (a.active[c]) a.act_idx[n++] = c;
-    DecState s;
-    s.n_active = n; s.r_rows = n * a.N; s.m_rows = n * step_rps(a.N, a.D);
-    s.stop = 0; s.width = a.width; s.steps = 0; s.error = 0; s.n_copy = 0;
-    s.accepted = s.produced = s.verified_positions = s.kv_prefix_positions = s.src_positions = 0;
-    *a.st = s;
-  }
-}
-
 // new_cache[c][0 .. len_c-2] = parent's cache [0 .. len_p-2] ++ parent's front row ++ parent's accepted draft rows.
 struct TreeCacheArgs {
   const int* len; const int* parent; const int* parent_draft; const int* prev_len; const uint8_t* active;
@@ -2579,27 +2550,6 @@ __global__ __launch_bounds__(256) void k_tree_cache(TreeCacheArgs a) {
     *reinterpret_cast<float4*>(kn + (size_t)(n_old + j) * a.d + col) = *reinterpret_cast<const float4*>(q + a.d + col);
     *reinterpret_cast<float4*>(vn + (size_t)(n_old + j) * a.d + col) = *reinterpret_cast<const float4*>(q + 2 * a.d + col);
   }
-}
-
-// remember which compact slot every candidate had in this step (the next step's cache build needs it)
-__global__ void k_tree_slots(const DecState* st, const int* act_idx, int* slot_of, const int* len, int* prev_len, int n_cand) {
-  for (int i = threadIdx.x; i < n_cand; i += blockDim.x) { slot_of[i] = -1; prev_len[i] = len[i]; }   // single block
-  __syncthreads();
-  for (int s = threadIdx.x; s < st->n_active; s += blockDim.x) slot_of[act_idx[s]] = s;
-}
-
-// logits of the step rows -> [n_cand, N, D+1, V] (position 0 of every draft is the shared front row)
-__global__ __launch_bounds__(256) void k_tree_logits(const float* logits, int V, const DecState* st, const int* act_idx, int N, int D,
-                                                     float* out) {
-  const int slot = blockIdx.x;
-  if (slot >= st->n_active) return;
-  const int c = act_idx[slot];
-  const int RPS = step_rps(N, D), D1 = D + 1;
-  const int n = blockIdx.y / D1, j = blockIdx.y % D1;
-  const int srow = (j == 0) ? 0 : 1 + n * D + (j - 1);
-  const float* src = logits + ((size_t)slot * RPS + srow) * V;
-  float* dst = out + (((size_t)c * N + n) * D1 + j) * V;
-  for (int v = threadIdx.x; v < V; v += blockDim.x) dst[v] = src[v];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2858,6 +2808,88 @@ __global__ void k_bs_init(int64_t* cand_next, int ld, int* len_next, uint8_t* fi
   if (tid == 0) {
     cnt->model_calls = 0; cnt->input_lines = 0; cnt->running_rows = 0; cnt->verified_positions = 0; cnt->executed_positions = 0;
     cnt->kv_prefix_positions = 0; cnt->running_cands = 0; cnt->max_group = 0; cnt->pad_ = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Standard beam search (standard_decoding.py:131-171): one workgroup per source.  total[k][v] =
+// score[k] + log(softmax(logits of candidate k))[v]  (finished candidates: the artificial "35 on PAD" row, :133-135), the
+// beam best of the beam*V totals best first (ties: lower flat index), and the new rows: parent's tokens + the new token.
+struct BeamStepArgs {
+  const float* logits; int V;                   // the step's logits, one row per running candidate (compact order)
+  const int* slot_of; const uint8_t* finished; const float* score;   // [n_cand]
+  const int* gen; int ld; int width;            // current rows [n_cand, ld], `width` tokens each
+  int B, beam, K, pad, eos;
+  int64_t* new_cand; float* new_score; int* parent; int* new_len; uint8_t* new_finished; int* parent_draft;
+  int* summary;                                 // [0] += new candidates holding EOS
+};
+
+__global__ __launch_bounds__(256) void k_beam_step(BeamStepArgs a) {
+  extern __shared__ float tot[];                // [beam * V]
+  __shared__ float s_best[4];
+  __shared__ int s_bi[4];
+  __shared__ int s_sel;
+  const int b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = wave; k < a.beam; k += 4) {
+    const int c = b * a.beam + k;
+    const bool fin = a.finished[c] != 0;
+    const float* row = fin ? nullptr : a.logits + (size_t)a.slot_of[c] * a.V;
+    float m = -INFINITY;
+    for (int v = lane; v < a.V; v += 64) m = fmaxf(m, fin ? (v == a.pad ? 35.0f : 0.0f) : row[v]);
+    m = wave_max(m);
+    float z = 0.f;
+    for (int v = lane; v < a.V; v += 64) z += expf((fin ? (v == a.pad ? 35.0f : 0.0f) : row[v]) - m);
+    z = wave_sum(z);
+    const float sc = a.score[c];
+    for (int v = lane; v < a.V; v += 64) {
+      const float x = fin ? (v == a.pad ? 35.0f : 0.0f) : row[v];
+      tot[k * a.V + v] = sc + logf(expf(x - m) / z);
+    }
+  }
+  __syncthreads();
+  const int n = a.beam * a.V;
+  for (int r = 0; r < a.K; ++r) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float v = tot[i];
+      if (v > best) { best = v; bi = i; }       // ascending i per thread: the first of equal values stays
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { s_best[wave] = best; s_bi[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int sel = s_bi[0];
+      float bv = s_best[0];
+      for (int w = 1; w < 4; ++w)
+        if (s_best[w] > bv || (s_best[w] == bv && s_bi[w] < sel)) { sel = s_bi[w]; bv = s_best[w]; }
+      if (sel == 0x7fffffff) sel = 0;           // every total is -inf / NaN: keep the indexing in range
+      s_sel = sel;
+    }
+    __syncthreads();
+    const int sel = s_sel;
+    const int k = sel / a.V, tok = sel % a.V;
+    const int c = b * a.beam + k, out = b * a.K + r;
+    const int* root = a.gen + (size_t)c * a.ld;
+    int64_t* dst = a.new_cand + (size_t)out * a.ld;
+    for (int col = threadIdx.x; col < a.ld; col += 256) dst[col] = col < a.width ? (int64_t)root[col] : (col == a.width ? (int64_t)tok : (int64_t)a.pad);
+    if (threadIdx.x == 0) {
+      a.new_score[out] = tot[sel];
+      a.parent[out] = c;
+      a.parent_draft[out] = 0;
+      a.new_len[out] = a.width + 1;
+      const bool has_eos = a.finished[c] || tok == a.eos;
+      a.new_finished[out] = has_eos ? 1 : 0;
+      if (has_eos) atomicAdd(&a.summary[0], 1);
+      tot[sel] = -INFINITY;
+    }
+    __syncthreads();
   }
 }
 

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from .model import NativeTransformer, TreeDecoder
+from .model import NativeTransformer
 
 
 def _need_native(model) -> NativeTransformer:
@@ -298,9 +298,8 @@ class TranslationInferenceGreedy:
 
 
 class TranslationInferenceBeamSearch:
-    """Standard beam search (src/decoding/standard_decoding.py:58-174): the decoder runs on a per-hypothesis KV cache
-    (ttx_tree_begin / ttx_tree_step: encoder and cross K/V once per source); the beam update of a step is array algebra
-    on the device."""
+    """Drop-in for src/decoding/standard_decoding.py:58-174: the whole loop runs in ttx_beam_generate (per-hypothesis KV
+    cache, encoder and cross K/V once per source, log-softmax + top-beam + row assembly in one kernel per step)."""
 
     def __init__(self, model, beam_size: int, max_len: int, pad_token: int, bos_token: int, eos_token: int):
         assert max_len > 1
@@ -317,42 +316,17 @@ class TranslationInferenceBeamSearch:
 
     def generate(self, src: torch.Tensor) -> torch.Tensor:
         m, K = self.model, self.beam_size
-        dev = m.device
-        src = src.to(dev, torch.int64)
+        src = src.to(m.device, torch.int64).contiguous()
         m.check_tokens(src)
-        B = src.size(0)
-        pad_col = m.src_pad_token_i                                   # standard_decoding.py:135
-        tree = TreeDecoder(m, src, B * K, self.max_len, 1, 0)
-        y0 = torch.full((B, 1), self.bos_token, dtype=src.dtype, device=dev)
-        ones = torch.ones(B, dtype=torch.int32, device=dev)
-        first = tree.step(y0, ones, -ones, 0 * ones, torch.arange(B, device=dev), ones.bool(), None, 1, 0)[:, 0]   # :102
-        self.b_sz += B
-        self.model_calls_num += 1
-        self.given_tokens += int((src != pad_col).sum())
-        V = first.size(-1)
-        score, tok = torch.log(torch.softmax(first[:, 0, :], dim=-1)).topk(K, dim=-1, sorted=True)
-        y = torch.cat([torch.full((B * K, 1), self.bos_token, dtype=src.dtype, device=dev), tok.reshape(-1, 1)], dim=1)
-        # the reference re-encodes the source once per beam (:120-124); the rows are identical, so the HIP path
-        # encodes once and lets the K beams of a source share that memory row
-        owner = torch.arange(B, device=dev).repeat_interleave(K)
-        prev_parent = owner.clone()                                   # row (b,k) extends the <BOS> row of source b
-        for _ in range(self.max_len - 2):
-            alive = ~((y == self.eos_token).any(dim=1))
-            self.b_sz += int(alive.sum())
-            step = torch.zeros((B * K, V), dtype=torch.float32, device=dev)
-            step[:, pad_col] = 35.0
-            length = torch.full((B * K,), y.size(1), dtype=torch.int32, device=dev)
-            out = tree.step(y, length, prev_parent, torch.zeros_like(length), owner, alive, None, 1, 0)[:, 0, 0]
-            step[alive] = out[alive]
-            self.model_calls_num += 1
-            total = (score.unsqueeze(-1) + torch.log(torch.softmax(step, dim=-1)).reshape(B, K, V)).reshape(B, K * V)
-            score, flat = total.topk(K, dim=-1, sorted=True)
-            parent = torch.div(flat, V, rounding_mode="floor") + torch.arange(B, device=dev).unsqueeze(1) * K
-            prev_parent = parent.reshape(-1)
-            y = torch.cat([y[prev_parent], (flat % V).reshape(-1, 1)], dim=1)
-            if bool((y == self.eos_token).any(dim=1).all()):
-                break
-        return y.reshape(B, K, -1)
+        B, Ls = src.shape
+        out = torch.empty((B, K, self.max_len), dtype=torch.int64, device=m.device)
+        p = N.BeamSearchParams(self.max_len, K, self.pad_token, self.bos_token, self.eos_token)
+        st = N.BeamSearchStats()
+        N.check(m._lib.ttx_beam_generate(m.session, src.data_ptr(), B, Ls, C.byref(p), out.data_ptr(), C.byref(st), m._stream()))
+        self.model_calls_num += int(st.model_calls)
+        self.b_sz += int(st.running_rows)
+        self.given_tokens += int((src != m.src_pad_token_i).sum())
+        return out[:, :, :int(st.out_width)].contiguous()
 
 
 class TranslationInferenceBeamSearchSpeculative:

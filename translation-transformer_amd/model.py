@@ -238,38 +238,3 @@ class NativeTransformer:
                                           max_draft_len, eos_token_idx, pad_token_idx, replace_token_idx,
                                           out.data_ptr(), self._stream()))
         return out
-
-
-class TreeDecoder:
-    """KV-cached decoder for the beam paths (ttx_tree_begin / ttx_tree_step): one instance per ``generate`` call."""
-
-    def __init__(self, model: NativeTransformer, src: torch.Tensor, max_cand: int, max_len: int, n_drafts: int,
-                 draft_len: int):
-        self.m = model
-        src = model._tokens(src)
-        self.B, self.Ls = src.shape
-        self.max_cand, self.N, self.D = int(max_cand), int(n_drafts), int(draft_len)
-        N.check(model._lib.ttx_tree_begin(model.session, src.data_ptr(), self.B, self.Ls, self.max_cand, int(max_len),
-                                          self.N, self.D, model._stream()))
-
-    def step(self, cand: torch.Tensor, length: torch.Tensor, parent: torch.Tensor, parent_draft: torch.Tensor,
-             src_row: torch.Tensor, active: torch.Tensor, drafts: torch.Tensor | None, n_slots: int, draft_len: int):
-        """cand Long[n,width]; length/parent/parent_draft/src_row int[n]; active bool[n]; drafts Long[n,n_slots,draft_len]
-        -> logits fp32 [n, n_slots, draft_len+1, V] (rows of inactive candidates are zeros)."""
-        m = self.m
-        dev = m.device
-        cand = cand.to(dev, torch.int64).contiguous()
-        n, width = cand.shape
-        i32 = lambda t: t.to(dev, torch.int32).contiguous()  # noqa: E731
-        length, parent, parent_draft, src_row = i32(length), i32(parent), i32(parent_draft), i32(src_row)
-        act = active.to(dev, torch.uint8).contiguous()
-        dptr = None
-        if draft_len > 0:
-            drafts = drafts.to(dev, torch.int64).contiguous()
-            assert drafts.shape == (n, n_slots, draft_len)
-            dptr = drafts.data_ptr()
-        out = torch.zeros((n, n_slots, draft_len + 1, m.tgt_vocab_size), dtype=torch.float32, device=dev)
-        N.check(m._lib.ttx_tree_step(m.session, cand.data_ptr(), n, width, length.data_ptr(), parent.data_ptr(),
-                                     parent_draft.data_ptr(), src_row.data_ptr(), act.data_ptr(), dptr, n_slots, draft_len,
-                                     out.data_ptr(), m._stream()))
-        return out
