@@ -61,9 +61,11 @@ def main():
     rows = load_trace(a.trace)
     stream, per = pick_stream(rows, int(roof["launches"]))
     print(f"command: {a.command}")
-    print(f"bench.py line of the profiled run: value {line['value']:.1f} {line['unit']}; roofline.launches {roof['launches']}, "
-          f"avg_launch_us {roof['avg_launch_us']:.2f} (HIP event pairs, {roof.get('event_pair_overhead_us', 0):.2f} us of it is what an empty "
-          f"pair measures), achieved {roof['achieved']:.1f} {roof['unit']} = {roof['frac']:.3f} of {roof['peak']}")
+    print(f"bench.py line of the profiled run (slower than an unprofiled run: the profiler serialises kernels): value {line['value']:.1f} "
+          f"{line['unit']}; roofline.launches {roof['launches']}, avg_launch_us {roof['avg_launch_us']:.2f} (HIP event pairs net of the "
+          f"{roof.get('event_pair_overhead_us', 0):.2f} us an empty pair measures; raw pairs "
+          f"{roof.get('avg_launch_us_raw_event_pairs', float('nan')):.2f} us), achieved {roof['achieved']:.1f} {roof['unit']} = "
+          f"{roof['frac']:.3f} of {roof['peak']}")
     print("GEMM launches per stream in the trace: " + ", ".join(f"stream {s}: {n}" for s, n in sorted(per.items(), key=lambda kv: -kv[1])))
     print(f"-> roofline pass = stream {stream} ({per[stream]} GEMM launches; bench.py counted {roof['launches']})")
     sel = [r for r in rows if r["stream"] == stream]
@@ -74,8 +76,8 @@ def main():
     ach = flops / (tot * 1e-9) / 1e12 if tot else 0.0
     print(f"GEMM launches on that stream: {len(gem)}, total {tot / 1e6:.2f} ms, average {avg_us:.2f} us per launch (rocprofv3 kernel trace)")
     print(f"algorithmic GEMM work of the pass (bench.py counters): {flops / 1e12:.3f} TFLOP -> {ach:.1f} TFLOP/s = {ach / roof['peak']:.3f} "
-          f"of the {roof['peak']} TFLOP/s fp32 MFMA peak by the trace ({roof['frac']:.3f} by raw event pairs, "
-          f"{roof.get('achieved_overhead_removed', 0) / roof['peak']:.3f} with the empty-pair cost removed)")
+          f"of the {roof['peak']} TFLOP/s fp32 MFMA peak by the trace (bench.py, same run: {roof['frac']:.3f} net of the event-pair "
+          f"overhead, {roof.get('frac_raw_event_pairs', float('nan')):.3f} by raw event pairs)")
     allk = defaultdict(lambda: [0, 0])
     for r in sel:
         allk[r["name"]][0] += 1
