@@ -195,3 +195,72 @@ def test_config_c3_full_size_matches_oracle(tta):
         n_diff += d
         n_total += t
     assert n_diff <= 0.05 * n_total
+
+
+@pytest.mark.parametrize("smart", [False, True])
+def test_short_max_len_shrinking_draft_length_matches_oracle(tta, smart):
+    """max_len so small that possible_draft_len falls below draft_len near the end (speculative_decoding.py:476): the draft
+    slots, the step's row layout and the cache hand-over change length between iterations; unfinished hypotheses stay in the
+    result.  Every hypothesis and the counters against the oracle (tiny model)."""
+    from oracle.model import OracleTransformer, config_from_state
+    from oracle.spec_beam import BeamSearchSpeculativeOracle
+    st, cfg = tiny_state()
+    native = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    oracle = OracleTransformer(config_from_state(st, cfg["num_heads"]), st)
+    src, _, c, V = fixture_tokens()
+    checked = 0
+    for max_len, nbest, N, D, rows in ((12, 3, 3, 10, [0, 2, 4]), (20, 5, 2, 10, [3, 5]), (33, 3, 5, 17, [2, 6, 8, 9]), (7, 2, 1, 5, [4])):
+        sel = src[rows]
+        sel = sel[:, :int((sel != PAD).sum(1).max())]
+        ref = BeamSearchSpeculativeOracle(oracle, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=300)
+        exp = ref.generate(sel).numpy()
+        g = tta.TranslationInferenceBeamSearchSpeculative(native, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=300)
+        out = g.generate(sel.cuda()).cpu().numpy()
+        assert out.shape == exp.shape, (max_len, out.shape, exp.shape)
+        np.testing.assert_array_equal(out, exp, err_msg=f"max_len {max_len}")
+        assert g.model_calls_num == ref.model_calls_num and g.accepted_tokens_num == ref.accepted_tokens_num
+        assert g.produced_non_pad_tokens == ref.produced_non_pad_tokens
+        checked += out.shape[0] * out.shape[1]
+    assert checked > 20
+
+
+def test_guards_and_reference_errors(tta):
+    st, cfg = tiny_state()
+    native = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    src, _, c, V = fixture_tokens()
+    one = src[1:2, :int((src[1] != PAD).sum())].cuda()
+    # fixture row 1 at n_best = 5: a low-ranked candidate keeps emitting PAD before any EOS — the reference's loop never ends
+    # (tests/golden/make_golden.py:section_spec_beam); the max_steps guard turns that into an error
+    g = tta.TranslationInferenceBeamSearchSpeculative(native, 150, 5, 10, 7, V, False, PAD, BOS, EOS, c, max_steps=60)
+    with pytest.raises(RuntimeError, match="max_steps"):
+        g.generate(one)
+    # where the reference asserts / raises
+    with pytest.raises(tta.ReferenceError_):          # smart drafts need src.shape[1] - 5 > 0 windows (drafting.py:39)
+        tta.TranslationInferenceBeamSearchSpeculative(native, 150, 3, 10, 3, V, True, PAD, BOS, EOS, c).generate(one[:, :5])
+    with pytest.raises(tta.ReferenceError_):          # max_len < 3: the loop body never runs, `new_candidates` is unbound
+        tta.TranslationInferenceBeamSearchSpeculative(native, 2, 3, 10, 3, V, False, PAD, BOS, EOS, c).generate(one)
+    with pytest.raises(tta.TtxError):                 # more draft slots than the bookkeeping kernels hold
+        tta.TranslationInferenceBeamSearchSpeculative(native, 150, 3, 10, 65, V, False, PAD, BOS, EOS, c).generate(one)
+    # the session is still usable afterwards
+    ok = tta.TranslationInferenceBeamSearchSpeculative(native, 150, 3, 10, 3, V, False, PAD, BOS, EOS, c, max_steps=300)
+    out = ok.generate(src[2:3, :int((src[2] != PAD).sum())].cuda())
+    assert out.shape[:2] == (1, 3) and bool((out[0, 0] == EOS).any())
+
+
+def test_standard_beam_search_small_cases_match_oracle(tta):
+    """Native standard beam search at edge shapes: beam 1, a single source, max_len shorter than the targets."""
+    from oracle.model import OracleTransformer, config_from_state
+    from oracle.decoding import BeamSearchOracle
+    st, cfg = tiny_state()
+    native = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    oracle = OracleTransformer(config_from_state(st, cfg["num_heads"]), st)
+    src, _, _, _ = fixture_tokens()
+    for beam, max_len, rows in ((1, 150, [0, 3]), (4, 9, [2]), (7, 40, [5, 6, 9]), (2, 3, [1])):
+        sel = src[rows]
+        sel = sel[:, :int((sel != PAD).sum(1).max())]
+        ref = BeamSearchOracle(oracle, beam, max_len, PAD, BOS, EOS)
+        exp = ref.generate(sel).numpy()
+        g = tta.TranslationInferenceBeamSearch(native, beam, max_len, PAD, BOS, EOS)
+        out = g.generate(sel.cuda()).cpu().numpy()
+        np.testing.assert_array_equal(out, exp, err_msg=f"beam {beam} max_len {max_len}")
+        assert g.model_calls_num == ref.model_calls_num
