@@ -411,6 +411,16 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
 #pragma unroll
   for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; }
   const int aoff = (wm * 64 + r) * LDT + 4 * h, boff = (wn * WN + r) * LDT + 4 * h;
+#ifdef TTX_G4_STAGGER
+  // Two workgroups share a CU.  Dispatched together they run in phase: both in their prologue, both in their epilogue at
+  // the same time, the MFMA pipe idle then.  The second half of the first wave of workgroups (the ones that land beside
+  // workgroups 0..255) starts half a tile late; later workgroups inherit the offset from the slots they take over.
+  {
+    const int lin0 = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin0 >= 256 && lin0 < 512)
+      for (int q = 0; q < TTX_G4_STAGGER; ++q) __builtin_amdgcn_s_sleep(100);      // 100 x 64 cycles each
+  }
+#endif
 #ifdef TTX_G4_PRIO
   // Two workgroups share a CU (one wave of each per SIMD).  With equal priority the SIMD alternates between their
   // MFMAs, both advance in lockstep and reach their LDS/barrier phases together, leaving the MFMA pipe idle then.
@@ -421,20 +431,33 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
   if (s_prio) __builtin_amdgcn_s_setprio(3);
 #endif
 
-  auto mma = [&](int buf) {
+  // One 32-deep K tile: 16 MFMAs per 8 k's.  `during(q)` (q = 0..3) runs after the first MFMA group of every 8-k
+  // step: the LDS writes of the NEXT tile go there, between MFMAs, so that they cost no MFMA time (the matrix pipe runs
+  // on while the wave issues them).
+  auto mma = [&](int buf, auto&& during) {
     const float* ap = As[buf] + aoff;
     const float* bp = Bs[buf] + boff;
+    // fragments of the 8-k step after the current one are read from LDS while the current step's MFMAs run
+    float4 a0 = *reinterpret_cast<const float4*>(ap);
+    float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDT);
+    float4 b0 = *reinterpret_cast<const float4*>(bp);
+    float4 b1 = b0;
+    if constexpr (BN == 128) b1 = *reinterpret_cast<const float4*>(bp + 32 * LDT);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 8) {
-      const float4 a0 = *reinterpret_cast<const float4*>(ap + kk);
-      const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDT + kk);
-      const float4 b0 = *reinterpret_cast<const float4*>(bp + kk);
+      float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+      if (kk + 8 < BK) {
+        na0 = *reinterpret_cast<const float4*>(ap + kk + 8);
+        na1 = *reinterpret_cast<const float4*>(ap + 32 * LDT + kk + 8);
+        nb0 = *reinterpret_cast<const float4*>(bp + kk + 8);
+        if constexpr (BN == 128) nb1 = *reinterpret_cast<const float4*>(bp + 32 * LDT + kk + 8);
+      }
       if constexpr (BN == 128) {
-        const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDT + kk);
         c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
         c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, c01, 0, 0, 0);
         c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
         c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, c11, 0, 0, 0);
+        during(kk >> 3);
         c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
         c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, c01, 0, 0, 0);
         c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
@@ -450,6 +473,7 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
       } else {
         c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
         c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
+        during(kk >> 3);
         c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
         c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
         c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
@@ -457,7 +481,17 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
         c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
         c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
       }
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
+  };
+  // quarter q of a tile's LDS writes (two float4 of A's 128 rows, one or two of B's rows)
+  auto lstore_q = [&](const G4Frag& f, int buf, int q) {
+    float* as = As[buf] + lr * LDT + lc;
+    float* bs = Bs[buf] + lr * LDT + lc;
+    if (q == 0) { *reinterpret_cast<float4*>(as) = f.a0; *reinterpret_cast<float4*>(bs) = f.b0; }
+    else if (q == 1) { *reinterpret_cast<float4*>(as + 32 * LDT) = f.a1; *reinterpret_cast<float4*>(bs + 32 * LDT) = f.b1; }
+    else if (q == 2) { *reinterpret_cast<float4*>(as + 64 * LDT) = f.a2; if constexpr (BN == 128) *reinterpret_cast<float4*>(bs + 64 * LDT) = f.b2; }
+    else { *reinterpret_cast<float4*>(as + 96 * LDT) = f.a3; if constexpr (BN == 128) *reinterpret_cast<float4*>(bs + 96 * LDT) = f.b3; }
   };
   // two register tiles in flight (static slots, clamped refills: same shape as k_gemm2's ring): a tile's loads are
   // issued two MFMA blocks (~3.4 us) before its LDS write.  The K range is a multiple of 64: ntiles is even.
@@ -477,6 +511,7 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
 #define TTX_G4OUTER(k) do { } while (0)
 #endif
   TTX_G4OUTER(1);
+#ifdef TTX_G4_NO_OVERLAP
   for (int i = 0; i < ntiles; i += 2) {
     TTX_G4STAMP(0);
     lstore(f0, 0);
@@ -487,7 +522,7 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     TTX_G4STAMP(2);
     __syncthreads();
     TTX_G4STAMP(3);
-    mma(0);
+    mma(0, [](int) {});
     TTX_G4STAMP(4);
     lstore(f1, 1);
     asm volatile("" ::: "memory");
@@ -495,9 +530,30 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     TTX_G4STAMP(5);
     __syncthreads();
     TTX_G4STAMP(6);
-    mma(1);
+    mma(1, [](int) {});
     TTX_G4STAMP(7);
   }
+#else
+  // Tile i is computed from one LDS buffer while tile i + 1 is written into the other BETWEEN the MFMAs (after the
+  // barrier that ends a phase every wave has finished reading the buffer the next phase overwrites), and the registers
+  // just emptied are refilled from global memory for tile i + 2: LDS writes, global loads and MFMAs overlap inside every
+  // wave instead of only across the two workgroups of a CU.
+  lstore(f0, 0);
+  asm volatile("" ::: "memory");
+  f0 = gload(min(2, last));
+  TTX_G4OUTER(2);
+  __syncthreads();
+  for (int i = 0; i < ntiles; i += 2) {
+    mma(0, [&](int q) { lstore_q(f1, 1, q); });
+    asm volatile("" ::: "memory");
+    f1 = gload(min(i + 3, last));
+    __syncthreads();
+    mma(1, [&](int q) { lstore_q(f0, 0, q); });          // tile i + 2 (a clamped repeat of the last tile at the end: never read)
+    asm volatile("" ::: "memory");
+    f0 = gload(min(i + 4, last));
+    __syncthreads();
+  }
+#endif
   TTX_G4OUTER(3);
 #undef TTX_G4STAMP
 
