@@ -17,8 +17,8 @@ shapes = [("FFN1", 2048, 256, 0), ("QKV", 768, 256, 0), ("dxd", 256, 256, 1), ("
 for M in Ms:
     for name, N, K, S in shapes:
         row = f"M={M:5d} {name:8s} N={N:4d} K={K:4d} S={S}:"
-        for variant in (2, 4, 46, 24):
-            if variant == 24 and (K // max(S, 1)) % 256:
+        for variant in (2, 4, 46, 24, 66):
+            if variant in (24, 66) and (K // max(S, 1)) % 256:
                 continue
             us, diff = C.c_double(), C.c_double()
             rc = lib.ttx_debug_gemm_bench(m.session, M, N, K, S, variant, 50, C.byref(us), C.byref(diff))

@@ -324,6 +324,7 @@ struct ttx_session {
   // 39.8 -> 33.8 us under these thresholds; 0 = never a 128-row tiling.
   int big_min_tiles = 400;
   int big_wide_tiles = 480;
+  bool ffn_b6 = false;             // TTX_FFN_BF16X6=1 (experiment): the FFN pair's products from bf16 pieces (k_gemm24_b6)
   int proj_split = 1;              // largest split-K factor of the step's d x d projections on the 64x64 kernel
   int gemm3_max_n = 0;             // step GEMMs at most this wide use the 32x32 kernel (k_gemm3); 0: none
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -415,6 +416,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   if (const char* fl = getenv("TTX_FUSE_LN_MIN_ROWS")) s->fuse_ln_min_rows = std::max(0, atoi(fl));
   if (const char* bt = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(bt));
   if (const char* bw = getenv("TTX_BIG_WIDE_TILES")) s->big_wide_tiles = std::max(0, atoi(bw));
+  if (const char* b6 = getenv("TTX_FFN_BF16X6")) s->ffn_b6 = atoi(b6) != 0;
   s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
   s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
@@ -510,6 +512,12 @@ static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, 
       case 128: hipLaunchKernelGGL((k_gemm3<128>), grid, dim3(256), 0, st, a); break;
       default: hipLaunchKernelGGL((k_gemm3<0>), grid, dim3(256), 0, st, a); break;
     }
+  } else if (s->ffn_b6 && !s->gemm_v1 && a.k_per_split % 256 == 0 && (N == s->m->cfg.feedforward_dim || K == s->m->cfg.feedforward_dim)) {
+    // experiment: both FFN GEMMs (encoder and decoder, every tiling) with products from bf16 pieces
+    a.big_min_tiles = s->big_min_tiles;
+    dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
+    if (a.k_per_split == 256) hipLaunchKernelGGL((k_gemm24_b6<4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm24_b6<0>), grid, dim3(256), 0, st, a);
   } else if (a.k_per_split % 256 == 0 && !s->gemm_v1 && s->big_min_tiles > 0 &&
              (long long)cdiv(Mmax, 128) * cdiv(N, 64) * S >= std::min(s->big_min_tiles, s->big_wide_tiles)) {
     // enough rows (at most) for the 128x128 tiling: one launch that picks the tiling from the live row count
@@ -2438,7 +2446,7 @@ extern "C" int ttx_debug_gemm_bench(ttx_session* s, int M, int N, int K, int spl
   a.relu = 0; a.raw = splits > 0 ? 1 : 0; a.k_per_split = K / S; a.slab_stride = (long long)M * N; a.dbg = nullptr;
   a.big_min_tiles = s->big_min_tiles;
   a.big_wide_tiles = s->big_wide_tiles;
-  if (variant == 24 && (K / S) % 256) return fail(TTX_ERR_INVALID, "variant 24 needs K / splits to be a multiple of 256");
+  if ((variant == 24 || variant == 66) && (K / S) % 256) return fail(TTX_ERR_INVALID, "variants 24 / 66 need K / splits to be a multiple of 256");
   hipStream_t st = nullptr;
   HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   auto launch = [&](int var, const GemmArgs& g) {
@@ -2448,6 +2456,10 @@ extern "C" int ttx_debug_gemm_bench(ttx_session* s, int M, int N, int K, int spl
       else hipLaunchKernelGGL((k_gemm24<0>), grid, dim3(256), 0, st, g);
     } else if (var == 4) {
       hipLaunchKernelGGL(k_gemm4, dim3(cdiv(N, 128), cdiv(M, 128), S), dim3(256), 0, st, g);
+    } else if (var == 66) {
+      dim3 grid(cdiv(N, 64), cdiv(M, 64), S);
+      if (g.k_per_split == 256) hipLaunchKernelGGL((k_gemm24_b6<4>), grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((k_gemm24_b6<0>), grid, dim3(256), 0, st, g);
     } else if (var == 46) {
       hipLaunchKernelGGL(k_gemm46, dim3(cdiv(N, 64), cdiv(M, 128), S), dim3(256), 0, st, g);
     } else if (var == 3) {

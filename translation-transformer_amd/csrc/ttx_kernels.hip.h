@@ -23,6 +23,47 @@ namespace ttx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------
+// fp32 product from bf16 pieces (opt-in experiment, TTX_FFN_BF16X6=1): an fp32 value splits EXACTLY into three
+// bf16 numbers (its 24 mantissa bits in groups of 8: hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits of
+// the rest), a bf16 x bf16 product is exact in fp32, and of the nine partial products of x * w the three smallest
+// (mid*lo, lo*mid, lo*lo: <= 2^-24 relative) are dropped — six v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) instead of
+// eight v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x the matrix-pipe rate at fp32-level error.  The operands stay fp32 in
+// memory and in LDS; a wave splits its own fragments in registers (about 5.5 VALU operations per value, issued beside the MFMAs).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct B6Frag { bf16x8 hi, mid, lo; };     // 8 consecutive k of one row / column
+
+__device__ __forceinline__ B6Frag b6_split(const float4& u, const float4& v) {
+  const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+  unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned xb = __float_as_uint(f[i]);
+    const float r1 = f[i] - __uint_as_float(xb & 0xffff0000u);           // exact
+    const unsigned r1b = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(r1b & 0xffff0000u);             // exact
+    hb[i] = xb; mb[i] = r1b; lb[i] = __float_as_uint(r2);
+  }
+  union { unsigned w[4]; bf16x8 v; } H, M, L;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                                            // element 2j in the low half, 2j+1 in the high half
+    H.w[j] = __builtin_amdgcn_perm(hb[2 * j + 1], hb[2 * j], 0x07060302u);
+    M.w[j] = __builtin_amdgcn_perm(mb[2 * j + 1], mb[2 * j], 0x07060302u);
+    L.w[j] = __builtin_amdgcn_perm(lb[2 * j + 1], lb[2 * j], 0x07060302u);
+  }
+  return B6Frag{H.v, M.v, L.v};
+}
+
+// c += a * b over 16 k's: smallest partial products first
+__device__ __forceinline__ void b6_mma(f32x16& c, const B6Frag& a, const B6Frag& b) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Device-resident loop state of one generate call (one per session).
 struct DecState {
   int n_active;        // Bc: rows still decoding
@@ -188,6 +229,17 @@ __device__ __forceinline__ void g2_store(const G2Frag& f, float* as, float* bs, 
   *reinterpret_cast<float4*>(&bs[(48 + lr) * LDT + lc]) = f.b3;
 }
 
+// the same tile from bf16 pieces: ap / bp point at the lane's row / column with offset 8h (not 4h): 8 consecutive k per lane
+template <int BK, int LDT>
+__device__ __forceinline__ void g2_mma_b6(f32x16& acc, const float* ap, const float* bp) {
+#pragma unroll
+  for (int kk = 0; kk < BK; kk += 16) {
+    const B6Frag a = b6_split(*reinterpret_cast<const float4*>(ap + kk), *reinterpret_cast<const float4*>(ap + kk + 4));
+    const B6Frag b = b6_split(*reinterpret_cast<const float4*>(bp + kk), *reinterpret_cast<const float4*>(bp + kk + 4));
+    b6_mma(acc, a, b);
+  }
+}
+
 template <int BK, int LDT>
 __device__ __forceinline__ void g2_mma(f32x16& acc, const float* ap, const float* bp) {
 #pragma unroll
@@ -205,7 +257,7 @@ __device__ __forceinline__ void g2_mma(f32x16& acc, const float* ap, const float
 // requested up front); NT = 0: any multiple of 4 tiles, ring slots refilled as they drain.
 constexpr int G24_SMEM_FLOATS = 2 * 2 * 128 * 36;      // 73 728 B: the larger of the two tilings' LDS images
 
-template <int NT>
+template <int NT, bool B6 = false>
 __device__ __forceinline__ void g2_body(const GemmArgs& a, const int M, const int bx, const int by, const int bz, float* smem) {
   constexpr int BM = 64, BN = 64, BK = 64, LDT = BK + 4, RING = 4;
   typedef float (*TileBufs)[BM * LDT];
@@ -245,13 +297,17 @@ __device__ __forceinline__ void g2_body(const GemmArgs& a, const int M, const in
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int aoff = (wm * 32 + r) * LDT + 4 * h, boff = (wn * 32 + r) * LDT + 4 * h;
+  const int aoff = (wm * 32 + r) * LDT + (B6 ? 8 : 4) * h, boff = (wn * 32 + r) * LDT + (B6 ? 8 : 4) * h;
+  auto tile_mma = [&](const float* ap, const float* bp) {
+    if constexpr (B6) g2_mma_b6<BK, LDT>(acc, ap, bp);
+    else g2_mma<BK, LDT>(acc, ap, bp);
+  };
 
   if constexpr (NT == 1) {
     const G2Frag f0 = g2_load(p, 0);
     g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
     __syncthreads();
-    g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
+    tile_mma(As[0] + aoff, Bs[0] + boff);
       if (TTX_G2_BUFS == 1) __syncthreads();
   } else if constexpr (NT == 2) {
     const G2Frag f0 = g2_load(p, 0);
@@ -259,13 +315,13 @@ __device__ __forceinline__ void g2_body(const GemmArgs& a, const int M, const in
     g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
     if (TTX_G2_BUFS == 2) g2_store<LDT>(f1, As[TTX_G2_BUFS - 1], Bs[TTX_G2_BUFS - 1], lr, lc);
     __syncthreads();
-    g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
+    tile_mma(As[0] + aoff, Bs[0] + boff);
     if (TTX_G2_BUFS == 1) {
       __syncthreads();
       g2_store<LDT>(f1, As[0], Bs[0], lr, lc);
       __syncthreads();
     }
-    g2_mma<BK, LDT>(acc, As[TTX_G2_BUFS - 1] + aoff, Bs[TTX_G2_BUFS - 1] + boff);
+    tile_mma(As[TTX_G2_BUFS - 1] + aoff, Bs[TTX_G2_BUFS - 1] + boff);
   } else {
     // ring of four register tiles, two LDS buffers; slot indices are compile-time (no register moves:
     // moving a pending load's destination would force a wait on it)
@@ -279,22 +335,22 @@ __device__ __forceinline__ void g2_body(const GemmArgs& a, const int M, const in
       if constexpr (NT == 0) f0 = g2_load(p, min(base + RING, last) * BK);      // clamped: branch-free refill
       __syncthreads();
       if (base == 0) TTX_GSTAMP(2);
-      g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
+      tile_mma(As[0] + aoff, Bs[0] + boff);
       if (TTX_G2_BUFS == 1) __syncthreads();
       g2_store<LDT>(f1, As[TTX_G2_BUFS - 1], Bs[TTX_G2_BUFS - 1], lr, lc);
       if constexpr (NT == 0) f1 = g2_load(p, min(base + RING + 1, last) * BK);
       __syncthreads();
-      g2_mma<BK, LDT>(acc, As[TTX_G2_BUFS - 1] + aoff, Bs[TTX_G2_BUFS - 1] + boff);
+      tile_mma(As[TTX_G2_BUFS - 1] + aoff, Bs[TTX_G2_BUFS - 1] + boff);
       if (TTX_G2_BUFS == 1) __syncthreads();
       g2_store<LDT>(f2, As[0], Bs[0], lr, lc);
       if constexpr (NT == 0) f2 = g2_load(p, min(base + RING + 2, last) * BK);
       __syncthreads();
-      g2_mma<BK, LDT>(acc, As[0] + aoff, Bs[0] + boff);
+      tile_mma(As[0] + aoff, Bs[0] + boff);
       if (TTX_G2_BUFS == 1) __syncthreads();
       g2_store<LDT>(f3, As[TTX_G2_BUFS - 1], Bs[TTX_G2_BUFS - 1], lr, lc);
       if constexpr (NT == 0) f3 = g2_load(p, min(base + RING + 3, last) * BK);
       __syncthreads();
-      g2_mma<BK, LDT>(acc, As[TTX_G2_BUFS - 1] + aoff, Bs[TTX_G2_BUFS - 1] + boff);
+      tile_mma(As[TTX_G2_BUFS - 1] + aoff, Bs[TTX_G2_BUFS - 1] + boff);
       if (TTX_G2_BUFS == 1) __syncthreads();
     }
   }
@@ -347,7 +403,7 @@ struct G4Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
 // fragment): twice the workgroups for the launches that are short of them (N <= 768 at a few thousand rows), so that two
 // are resident per CU and one's prologue / epilogue overlaps the other's MFMAs.  Same K order in one accumulator per
 // element as every other tiling: bit-identical results.
-template <int BN>
+template <int BN, bool B6 = false>
 __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const int bx, const int by, const int bz, float* smem) {
   constexpr int BM = 128, BK = 32, LDT = BK + 4;
   constexpr int WN = BN / 2;                      // columns per wave
@@ -410,7 +466,7 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
   f32x16 c00, c01, c10, c11;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; }
-  const int aoff = (wm * 64 + r) * LDT + 4 * h, boff = (wn * WN + r) * LDT + 4 * h;
+  const int aoff = (wm * 64 + r) * LDT + (B6 ? 8 : 4) * h, boff = (wn * WN + r) * LDT + (B6 ? 8 : 4) * h;
 #ifdef TTX_G4_STAGGER
   // Two workgroups share a CU.  Dispatched together they run in phase: both in their prologue, both in their epilogue at
   // the same time, the MFMA pipe idle then.  The second half of the first wave of workgroups (the ones that land beside
@@ -437,6 +493,26 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
   auto mma = [&](int buf, auto&& during) {
     const float* ap = As[buf] + aoff;
     const float* bp = Bs[buf] + boff;
+    if constexpr (B6) {
+      // bf16 pieces: two 16-k steps per tile, 8 consecutive k per lane; same K order in one accumulator per element for
+      // every tiling (g2_mma_b6): bit-identical across tilings like the fp32 path
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 16) {
+        const B6Frag fa0 = b6_split(*reinterpret_cast<const float4*>(ap + kk), *reinterpret_cast<const float4*>(ap + kk + 4));
+        const B6Frag fb0 = b6_split(*reinterpret_cast<const float4*>(bp + kk), *reinterpret_cast<const float4*>(bp + kk + 4));
+        b6_mma(c00, fa0, fb0);
+        during(kk >> 3);
+        const B6Frag fa1 = b6_split(*reinterpret_cast<const float4*>(ap + 32 * LDT + kk), *reinterpret_cast<const float4*>(ap + 32 * LDT + kk + 4));
+        b6_mma(c10, fa1, fb0);
+        during((kk >> 3) + 1);
+        if constexpr (BN == 128) {
+          const B6Frag fb1 = b6_split(*reinterpret_cast<const float4*>(bp + 32 * LDT + kk), *reinterpret_cast<const float4*>(bp + 32 * LDT + kk + 4));
+          b6_mma(c01, fa0, fb1);
+          b6_mma(c11, fa1, fb1);
+        }
+      }
+      return;
+    }
     // fragments of the 8-k step after the current one are read from LDS while the current step's MFMAs run
     float4 a0 = *reinterpret_cast<const float4*>(ap);
     float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDT);
@@ -643,6 +719,30 @@ __global__ __launch_bounds__(256) void k_gemm24(GemmArgs a) {
     else g4_body<64>(a, M, rem % nbx, rem / nbx, slice, smem);
   } else {
     g2_body<NT>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  }
+}
+
+// The same launch with every product formed from bf16 pieces (b6_split / b6_mma): opt-in experiment for the FFN pair.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_gemm24_b6(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[G24_SMEM_FLOATS];
+  const int M = a.m_ptr ? *a.m_ptr : a.M;
+  const int nby = (M + 127) >> 7;
+  const int big_tiles = nby * ((a.N + 127) >> 7) * (int)gridDim.z;
+  const int mid_tiles = nby * ((a.N + 63) >> 6) * (int)gridDim.z;
+  const bool wide = a.big_min_tiles > 0 && big_tiles >= a.big_wide_tiles;
+  if (wide || (a.big_min_tiles > 0 && mid_tiles >= a.big_min_tiles)) {
+    const int n_tiles = wide ? big_tiles : mid_tiles;
+    const int nbx = wide ? (a.N + 127) >> 7 : (a.N + 63) >> 6;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin >= n_tiles) return;
+    const int xb = n_tiles >> 3, xr = n_tiles & 7, xcd = lin & 7;
+    const int v = xcd * xb + min(xcd, xr) + (lin >> 3);
+    const int slice = v / (nbx * nby), rem = v - slice * (nbx * nby);
+    if (wide) g4_body<128, true>(a, M, rem % nbx, rem / nbx, slice, smem);
+    else g4_body<64, true>(a, M, rem % nbx, rem / nbx, slice, smem);
+  } else {
+    g2_body<NT, true>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
   }
 }
 
