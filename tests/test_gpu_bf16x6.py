@@ -28,3 +28,41 @@ def test_full_size_tests_stay_green_under_bf16x6_ffn():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_logit_error_against_float64_is_not_worse_than_the_fp32_path():
+    """Full-size model (d 256, FFN 2048, 4+4): pre-argmax logits of the fp32-MFMA path and of the bf16x6-FFN path against a
+    float64 evaluation of the same network (stock torch modules in double).  The experiment must not be less accurate than the
+    path it would replace: its error has to stay within 1.5x of the fp32 path's (both are ~1e-5 and far below the 1e-3 bar)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, str(ROOT))
+    import translation_transformer_amd as tta
+    from tools.train_synth import TrainModel
+    from util_models import full_state, fixture_tokens, PAD
+    st = {k: torch.from_numpy(v) for k, v in full_state().items()}
+    V = st["next_token_classifier.weight"].shape[0]
+    src, tgt, _, _ = fixture_tokens()
+    s, t = (src % V).clone(), (tgt[:, :40] % V).clone()
+    s[src == PAD] = PAD
+    t[tgt[:, :40] == PAD] = PAD
+    t[:, 0] = 1
+    ref = TrainModel(vocab=V).double()
+    ref.load_state_dict({k: v.double() for k, v in st.items()}, strict=True)
+    ref.eval()
+    with torch.no_grad():
+        want = ref(s, t)
+    keep = (t != PAD)                                     # positions whose logits the generators ever read
+    errs = {}
+    for mode in ("0", "1"):
+        os.environ["TTX_FFN_BF16X6"] = mode               # read when the session is created
+        try:
+            m = tta.NativeTransformer(st, 8, PAD, device=0)
+        finally:
+            os.environ.pop("TTX_FFN_BF16X6", None)
+        got = m(s.cuda(), t.cuda()).cpu().double()
+        errs[mode] = float((got - want).abs()[keep].max())
+        m.close()
+    print(f"max |logit - float64|: fp32 MFMA path {errs['0']:.3e}, bf16x6 FFN path {errs['1']:.3e}")
+    assert errs["0"] < 1e-3 and errs["1"] < 1e-3
+    assert errs["1"] <= 1.5 * errs["0"] + 1e-6

@@ -232,11 +232,22 @@ __device__ __forceinline__ void g2_store(const G2Frag& f, float* as, float* bs, 
 // the same tile from bf16 pieces: ap / bp point at the lane's row / column with offset 8h (not 4h): 8 consecutive k per lane
 template <int BK, int LDT>
 __device__ __forceinline__ void g2_mma_b6(f32x16& acc, const float* ap, const float* bp) {
+  B6Frag a = b6_split(*reinterpret_cast<const float4*>(ap), *reinterpret_cast<const float4*>(ap + 4));
+  B6Frag b = b6_split(*reinterpret_cast<const float4*>(bp), *reinterpret_cast<const float4*>(bp + 4));
 #pragma unroll
   for (int kk = 0; kk < BK; kk += 16) {
-    const B6Frag a = b6_split(*reinterpret_cast<const float4*>(ap + kk), *reinterpret_cast<const float4*>(ap + kk + 4));
-    const B6Frag b = b6_split(*reinterpret_cast<const float4*>(bp + kk), *reinterpret_cast<const float4*>(bp + kk + 4));
+    // the next step's fragments are split between the six MFMAs of this one (a 32x32 tile per wave has twice the split
+    // work per MFMA of the 128-row tilings: this path is VALU-bound)
+    const int kn = (kk + 16 < BK) ? kk + 16 : kk;
+    const B6Frag na = b6_split(*reinterpret_cast<const float4*>(ap + kn), *reinterpret_cast<const float4*>(ap + kn + 4));
+    const B6Frag nb = b6_split(*reinterpret_cast<const float4*>(bp + kn), *reinterpret_cast<const float4*>(bp + kn + 4));
     b6_mma(acc, a, b);
+#pragma unroll
+    for (int i_ = 0; i_ < 6; ++i_) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);
+    }
+    a = na; b = nb;
   }
 }
 
@@ -495,22 +506,47 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     const float* bp = Bs[buf] + boff;
     if constexpr (B6) {
       // bf16 pieces: two 16-k steps per tile, 8 consecutive k per lane; same K order in one accumulator per element for
-      // every tiling (g2_mma_b6): bit-identical across tilings like the fp32 path
+      // every tiling (g2_mma_b6): bit-identical across tilings like the fp32 path.  The split of the NEXT fragment (about 44
+      // VALU operations) is issued between the six MFMAs of the current accumulator update: one MFMA, eight VALU, ...
+      auto ldA = [&](int blk, int kk) { return b6_split(*reinterpret_cast<const float4*>(ap + blk * 32 * LDT + kk),
+                                                         *reinterpret_cast<const float4*>(ap + blk * 32 * LDT + kk + 4)); };
+      auto ldB = [&](int blk, int kk) { return b6_split(*reinterpret_cast<const float4*>(bp + blk * 32 * LDT + kk),
+                                                         *reinterpret_cast<const float4*>(bp + blk * 32 * LDT + kk + 4)); };
+#define TTX_B6_INTERLEAVE()                                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                         \
+      }
+      B6Frag fa0 = ldA(0, 0), fb0 = ldB(0, 0);
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 16) {
-        const B6Frag fa0 = b6_split(*reinterpret_cast<const float4*>(ap + kk), *reinterpret_cast<const float4*>(ap + kk + 4));
-        const B6Frag fb0 = b6_split(*reinterpret_cast<const float4*>(bp + kk), *reinterpret_cast<const float4*>(bp + kk + 4));
+        const B6Frag fa1 = ldA(1, kk);
         b6_mma(c00, fa0, fb0);
+        TTX_B6_INTERLEAVE();
         during(kk >> 3);
-        const B6Frag fa1 = b6_split(*reinterpret_cast<const float4*>(ap + 32 * LDT + kk), *reinterpret_cast<const float4*>(ap + 32 * LDT + kk + 4));
-        b6_mma(c10, fa1, fb0);
-        during((kk >> 3) + 1);
         if constexpr (BN == 128) {
-          const B6Frag fb1 = b6_split(*reinterpret_cast<const float4*>(bp + 32 * LDT + kk), *reinterpret_cast<const float4*>(bp + 32 * LDT + kk + 4));
+          const B6Frag fb1 = ldB(1, kk);
+          b6_mma(c10, fa1, fb0);
+          TTX_B6_INTERLEAVE();
+          during((kk >> 3) + 1);
+          const B6Frag na0 = (kk + 16 < BK) ? ldA(0, kk + 16) : fa0;
           b6_mma(c01, fa0, fb1);
+          TTX_B6_INTERLEAVE();
+          const B6Frag nb0 = (kk + 16 < BK) ? ldB(0, kk + 16) : fb0;
           b6_mma(c11, fa1, fb1);
+          TTX_B6_INTERLEAVE();
+          fa0 = na0; fb0 = nb0;
+        } else {
+          const B6Frag na0 = (kk + 16 < BK) ? ldA(0, kk + 16) : fa0;
+          const B6Frag nb0 = (kk + 16 < BK) ? ldB(0, kk + 16) : fb0;
+          b6_mma(c10, fa1, fb0);
+          TTX_B6_INTERLEAVE();
+          TTX_B6_INTERLEAVE();
+          during((kk >> 3) + 1);
+          fa0 = na0; fb0 = nb0;
         }
       }
+#undef TTX_B6_INTERLEAVE
       return;
     }
     // fragments of the 8-k step after the current one are read from LDS while the current step's MFMAs run
