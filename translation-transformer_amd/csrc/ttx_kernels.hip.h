@@ -32,23 +32,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct B6Frag { bf16x8 hi, mid, lo; };     // 8 consecutive k of one row / column
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ B6Frag b6_split(const float4& u, const float4& v) {
-  const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-  unsigned hb[8], mb[8], lb[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const unsigned xb = __float_as_uint(f[i]);
-    const float r1 = f[i] - __uint_as_float(xb & 0xffff0000u);           // exact
-    const unsigned r1b = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(r1b & 0xffff0000u);             // exact
-    hb[i] = xb; mb[i] = r1b; lb[i] = __float_as_uint(r2);
-  }
+  // pairs of values: the two exact subtractions per value are packed fp32 operations (v_pk_add_f32), the masks plain ANDs, and
+  // one v_perm_b32 per pair and piece packs the two upper halves into a bf16x2 register
+  const f32x2 x[4] = {{u.x, u.y}, {u.z, u.w}, {v.x, v.y}, {v.z, v.w}};
   union { unsigned w[4]; bf16x8 v; } H, M, L;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {                                            // element 2j in the low half, 2j+1 in the high half
-    H.w[j] = __builtin_amdgcn_perm(hb[2 * j + 1], hb[2 * j], 0x07060302u);
-    M.w[j] = __builtin_amdgcn_perm(mb[2 * j + 1], mb[2 * j], 0x07060302u);
-    L.w[j] = __builtin_amdgcn_perm(lb[2 * j + 1], lb[2 * j], 0x07060302u);
+  for (int j = 0; j < 4; ++j) {
+    const u32x2 xb = __builtin_bit_cast(u32x2, x[j]);
+    const f32x2 r1 = x[j] - __builtin_bit_cast(f32x2, xb & 0xffff0000u);          // exact
+    const u32x2 r1b = __builtin_bit_cast(u32x2, r1);
+    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, r1b & 0xffff0000u);           // exact
+    const u32x2 r2b = __builtin_bit_cast(u32x2, r2);
+    H.w[j] = __builtin_amdgcn_perm(xb.y, xb.x, 0x07060302u);                       // element 2j in the low half, 2j+1 in the high half
+    M.w[j] = __builtin_amdgcn_perm(r1b.y, r1b.x, 0x07060302u);
+    L.w[j] = __builtin_amdgcn_perm(r2b.y, r2b.x, 0x07060302u);
   }
   return B6Frag{H.v, M.v, L.v};
 }
@@ -515,7 +516,7 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
 #define TTX_B6_INTERLEAVE()                                                        \
       _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                           \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                         \
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                         \
       }
       B6Frag fa0 = ldA(0, 0), fb0 = ldB(0, 0);
 #pragma unroll
