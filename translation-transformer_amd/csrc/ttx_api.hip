@@ -1950,14 +1950,14 @@ static int beam_enqueue_iter(const BeamJob& j, bool first, int cur) {
   aa.per_cand = s->bs_per_cand.as<int>(); aa.drafts32 = s->drafts.as<int>(); aa.cnt = s->bs_cnt.as<BeamCounters>();
   aa.n_cand = j.n_cand; aa.N = j.N; aa.dl = dl; aa.K = j.K; aa.smart = j.smart ? 1 : 0; aa.nucleus = 0.9975f;
   aa.best_n = s->bs_best_n.as<int>(); aa.best_slot = s->bs_best_slot.as<int>(); aa.chosen = s->bs_chosen.as<int64_t>();
-  hipLaunchKernelGGL(k_bs_accept, dim3(MC), dim3(256), 0, st, aa);
+  hipLaunchKernelGGL(k_bs_accept, dim3(MC), dim3(BS_ACCEPT_THREADS), 0, st, aa);
   HIP_TRY(hipGetLastError());
   BeamLeaves2Args le{};
   le.logits = s->logits.as<float>(); le.V = V; le.finished = s->bs_fin.as<uint8_t>(); le.slot_of = s->t_slot_of.as<int>();
   le.best_n = s->bs_best_n.as<int>(); le.best_slot = s->bs_best_slot.as<int>(); le.drafts32 = s->drafts.as<int>();
   le.logp = s->bs_logp.as<float>(); le.n_cand = j.n_cand; le.N = j.N; le.dl = dl; le.K = j.K; le.bos = j.p.bos_token; le.pad = j.p.pad_token;
   le.leaf_score = s->leaf_score.as<float>(); le.leaf_tok = s->leaf_tok.as<int>(); le.leaf_cnt = s->leaf_cnt.as<int>();
-  hipLaunchKernelGGL(k_bs_leaves, dim3(MC), dim3(256), (size_t)2 * (dl + 1) * 4, st, le);
+  hipLaunchKernelGGL(k_bs_leaves, dim3(MC), dim3(BS_LEAVES_THREADS), (size_t)2 * (dl + 1) * 4, st, le);
   HIP_TRY(hipGetLastError());
   BeamSelectArgs<int> sa{s->leaf_score.as<float>(), s->leaf_tok.as<int>(), s->leaf_cnt.as<int>(), s->gen.as<int>(), j.gen_ld, j.gen_ld,
                          j.gen_ld, s->bs_len.as<int>(), s->bs_chosen.as<int64_t>(), s->bs_best_slot.as<int>(), s->bs_fin.as<uint8_t>(),

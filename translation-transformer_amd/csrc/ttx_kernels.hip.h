@@ -2539,11 +2539,11 @@ __global__ __launch_bounds__(256) void k_ragged_topk(RaggedTopkArgs a) {
 template <class RowPtr, class Chosen>
 __device__ __forceinline__ void beam_leaves_core(int c, int nacc, float root, int dl, int V, int K, int bos, RowPtr rowp, Chosen chosen,
                                                  float* leaf_score, int* leaf_tok, int* leaf_cnt, float* lp_kept) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = (int)(blockDim.x >> 6);
   const int dl1 = dl + 1;
   float* run = lp_kept + dl1;                 // [dl+1] sequential prefix sums
   // pass 1: per position softmax statistics, kept-token log-prob, and the surviving top-K (unsorted ranks)
-  for (int p = wave; p < dl1; p += 4) {
+  for (int p = wave; p < dl1; p += n_waves) {
     const float* row = rowp(p);
     int ki[NUC_MAX_KEEP];
     float kv[NUC_MAX_KEEP];
@@ -2637,6 +2637,8 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
   }
   __syncthreads();
   if (s_off[nseg] < a.K) { if (threadIdx.x == 0) a.summary[4] = 1; return; }   // the reference asserts len >= k
+  __shared__ int s_win[NUC_MAX_KEEP];          // strided entry of the r-th best leaf
+  __shared__ float s_wsc[NUC_MAX_KEEP];
   for (int r = 0; r < a.K; ++r) {
     float best = -INFINITY;
     int bc = 0x7fffffff, be = -1;
@@ -2662,41 +2664,45 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
         if (e2 < 0) continue;
         if (sel < 0 || s_best[w] > bv || (s_best[w] == bv && code[e2] < code[sel])) { sel = e2; bv = s_best[w]; }
       }
-      s_sel = sel;
-    }
-    __syncthreads();
-    const int sel = s_sel;
-    const int seg = sel / a.K, i = sel % a.K;
-    const int cl_local = seg / dl1, p = seg % dl1;
-    const int c = b * a.beam + cl_local;        // root candidate
-    const int out = b * a.K + r;                // new candidate index
-    const int tok = a.leaf_tok[((size_t)b * nseg + seg) * a.K + i];
-    const int lc = a.len[c];
-    const TokT* root = a.cand + (size_t)c * a.ld_in;
-    int64_t* dst = a.new_cand + (size_t)out * a.ld_out;
-    for (int col = threadIdx.x; col < a.width; col += blockDim.x) {
-      int64_t t = (int64_t)root[col];
-      const int j = col - lc;
-      if (j >= 0 && j <= a.dl) t = (j < p) ? a.chosen[(size_t)c * a.dl + j] : (j == p ? (int64_t)tok : (int64_t)a.pad);
-      dst[col] = t;
-    }
-    if (threadIdx.x == 0) {
-      a.new_logp[out] = sc[sel];
-      a.parent[out] = c;
-      a.parent_draft[out] = a.chosen_slot[c];
-      const int fin_root = a.finished[c];
-      a.mark[out] = fin_root ? -1 : p;
-      const bool has_eos = fin_root || tok == a.eos;       // accepted draft tokens are never EOS (drafting.py:65)
-      if (has_eos) atomicAdd(&a.summary[0], 1);
-      // PAD columns of the new row: everything after its last real token
-      const int real = (tok == a.pad) ? lc + p : lc + p + 1;
-      atomicMin(&a.summary[1], a.width - real);
-      if (a.new_len) { a.new_len[out] = real; a.new_finished[out] = has_eos ? 1 : 0; }
-      if (!fin_root) { atomicAdd(&a.summary[2], p); atomicAdd(&a.summary[3], 1); }
-      sc[sel] = -INFINITY;
+      s_win[r] = sel;
+      s_wsc[r] = sc[sel];
+      sc[sel] = -INFINITY;                     // taken
       code[sel] = 0x7fffffff;
     }
     __syncthreads();
+  }
+  // the K new rows, all at once: root tokens, the kept draft tokens, the leaf token
+  for (int e = threadIdx.x; e < a.K * a.width; e += blockDim.x) {
+    const int r = e / a.width, col = e - r * a.width;
+    const int sel = s_win[r];
+    const int seg = sel / a.K, i = sel % a.K;
+    const int cl_local = seg / dl1, p = seg % dl1;
+    const int c = b * a.beam + cl_local;
+    const int tok = a.leaf_tok[((size_t)b * nseg + seg) * a.K + i];
+    const int lc = a.len[c];
+    int64_t t = (int64_t)a.cand[(size_t)c * a.ld_in + col];
+    const int j = col - lc;
+    if (j >= 0 && j <= a.dl) t = (j < p) ? a.chosen[(size_t)c * a.dl + j] : (j == p ? (int64_t)tok : (int64_t)a.pad);
+    a.new_cand[(size_t)(b * a.K + r) * a.ld_out + col] = t;
+  }
+  for (int r = threadIdx.x; r < a.K; r += blockDim.x) {
+    const int sel = s_win[r];
+    const int seg = sel / a.K, i = sel % a.K;
+    const int cl_local = seg / dl1, p = seg % dl1;
+    const int c = b * a.beam + cl_local, out = b * a.K + r;
+    const int tok = a.leaf_tok[((size_t)b * nseg + seg) * a.K + i];
+    const int lc = a.len[c];
+    a.new_logp[out] = s_wsc[r];
+    a.parent[out] = c;
+    a.parent_draft[out] = a.chosen_slot[c];
+    const int fin_root = a.finished[c];
+    a.mark[out] = fin_root ? -1 : p;
+    const bool has_eos = fin_root || tok == a.eos;       // accepted draft tokens are never EOS (drafting.py:65)
+    if (has_eos) atomicAdd(&a.summary[0], 1);
+    const int real = (tok == a.pad) ? lc + p : lc + p + 1;   // PAD columns of the new row: everything after its last real token
+    atomicMin(&a.summary[1], a.width - real);
+    if (a.new_len) { a.new_len[out] = real; a.new_finished[out] = has_eos ? 1 : 0; }
+    if (!fin_root) { atomicAdd(&a.summary[2], p); atomicAdd(&a.summary[3], 1); }
   }
 }
 
@@ -2898,39 +2904,55 @@ struct BeamAcceptArgs {
   int* best_n; int* best_slot; int64_t* chosen;      // [max_cand], [max_cand], [max_cand, dl]
 };
 
-// One workgroup per candidate.  Accepted length of each of its drafts = leading draft tokens that are among the <= K
-// tokens inside the nucleus of their position (:539-548, :847-869; finished candidates see the artificial "35 on PAD"
-// logits, under which no draft token survives), then the best draft exactly as the reference's topk(1) picks it among
-// equal counts (ttx_select.h): over the N drafts, or in smart mode over the table padded with -1 to the longest group.
-__global__ __launch_bounds__(256) void k_bs_accept(BeamAcceptArgs a) {
+// One workgroup (16 waves) per candidate.  Accepted length of each of its drafts = leading draft tokens that are among the
+// <= K tokens inside the nucleus of their position (:539-548, :847-869; finished candidates see the artificial "35 on PAD"
+// logits, under which no draft token survives).  Every (draft, position) pair is tested by a wave of its own — the positions
+// are independent, only the count of LEADING hits matters — then the best draft exactly as the reference's topk(1) picks it
+// among equal counts (ttx_select.h): over the N drafts, or in smart mode over the table padded with -1 to the longest group.
+constexpr int BS_ACCEPT_THREADS = 1024;
+constexpr int BS_MAX_PAIRS = BS_MAX_SLOTS * 32;      // LDS hit flags: the kernel falls back to a per-draft walk beyond this
+__global__ __launch_bounds__(BS_ACCEPT_THREADS) void k_bs_accept(BeamAcceptArgs a) {
   __shared__ int s_nok[BS_MAX_SLOTS];
   __shared__ long long s_v[BS_MAX_SLOTS];
   __shared__ int s_ix[BS_MAX_SLOTS];
   __shared__ int s_best;
+  __shared__ unsigned char s_hit[BS_MAX_PAIRS];
   const int c = blockIdx.x;
   if (c >= a.n_cand) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
   const int pc = a.per_cand[c];
   const int RPS = step_rps(a.N, a.dl);
-  if (a.finished[c]) {
-    for (int i = threadIdx.x; i < pc; i += 256) s_nok[i] = 0;
-  } else {
-    const float* base = a.logits + (size_t)a.slot_of[c] * RPS * a.V;
-    for (int i = wave; i < pc; i += 4) {
-      const int* dr = a.drafts32 + ((size_t)c * a.N + i) * a.dl;
+  const bool fin = a.finished[c] != 0;
+  const float* base = fin ? nullptr : a.logits + (size_t)a.slot_of[c] * RPS * a.V;
+  auto hit_at = [&](int i, int j) -> bool {          // is token j of draft i inside the kept set of its position?
+    int ki[NUC_MAX_KEEP];
+    float kv[NUC_MAX_KEEP];
+    int nk;
+    const int srow = (j == 0) ? 0 : 1 + i * a.dl + (j - 1);
+    nucleus_select(base + (size_t)srow * a.V, a.V, a.nucleus, a.K, lane, ki, kv, nk);
+    const int tok = a.drafts32[((size_t)c * a.N + i) * a.dl + j];
+    bool hit = false;
+    for (int q = 0; q < nk; ++q) hit |= (ki[q] == tok);
+    return hit;
+  };
+  const int pairs = pc * a.dl;
+  if (fin) {
+    for (int i = threadIdx.x; i < pc; i += blockDim.x) s_nok[i] = 0;
+  } else if (pairs <= BS_MAX_PAIRS) {
+    for (int p = wave; p < pairs; p += n_waves) {
+      const bool h = hit_at(p / a.dl, p % a.dl);
+      if (lane == 0) s_hit[p] = h ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < pc; i += blockDim.x) {
       int ok = 0;
-      for (int j = 0; j < a.dl; ++j) {
-        int ki[NUC_MAX_KEEP];
-        float kv[NUC_MAX_KEEP];
-        int nk;
-        const int srow = (j == 0) ? 0 : 1 + i * a.dl + (j - 1);
-        nucleus_select(base + (size_t)srow * a.V, a.V, a.nucleus, a.K, lane, ki, kv, nk);
-        const int tok = dr[j];
-        bool hit = false;
-        for (int q = 0; q < nk; ++q) hit |= (ki[q] == tok);
-        if (!hit) break;
-        ++ok;
-      }
+      while (ok < a.dl && s_hit[i * a.dl + ok]) ++ok;
+      s_nok[i] = ok;
+    }
+  } else {
+    for (int i = wave; i < pc; i += n_waves) {        // very long drafts: walk each draft until its first miss
+      int ok = 0;
+      while (ok < a.dl && hit_at(i, ok)) ++ok;
       if (lane == 0) s_nok[i] = ok;
     }
   }
@@ -2945,7 +2967,7 @@ __global__ __launch_bounds__(256) void k_bs_accept(BeamAcceptArgs a) {
   }
   __syncthreads();
   const int best = s_best;
-  for (int j = threadIdx.x; j < a.dl; j += 256) a.chosen[(size_t)c * a.dl + j] = (int64_t)a.drafts32[((size_t)c * a.N + best) * a.dl + j];
+  for (int j = threadIdx.x; j < a.dl; j += blockDim.x) a.chosen[(size_t)c * a.dl + j] = (int64_t)a.drafts32[((size_t)c * a.N + best) * a.dl + j];
 }
 
 struct BeamLeaves2Args {
@@ -2957,13 +2979,14 @@ struct BeamLeaves2Args {
 
 // `sample` (:294-400) on the step's own logits rows.  A finished candidate has exactly one leaf: PAD at position 0 with
 // log-softmax(35 on PAD, 0 elsewhere)[PAD] = log(1 / (1 + (V-1) e^-35)), which is 0 in fp32.
-__global__ __launch_bounds__(256) void k_bs_leaves(BeamLeaves2Args a) {
+constexpr int BS_LEAVES_THREADS = 256;        // four waves share the positions of the chosen draft (16 waves measured slower: 122 vs 70 us)
+__global__ __launch_bounds__(BS_LEAVES_THREADS) void k_bs_leaves(BeamLeaves2Args a) {
   extern __shared__ float lp_kept[];
   const int c = blockIdx.x;
   if (c >= a.n_cand) return;
   const int dl1 = a.dl + 1;
   if (a.finished[c]) {
-    for (int p = threadIdx.x; p < dl1; p += 256) a.leaf_cnt[(size_t)c * dl1 + p] = (p == 0) ? 1 : 0;
+    for (int p = threadIdx.x; p < dl1; p += blockDim.x) a.leaf_cnt[(size_t)c * dl1 + p] = (p == 0) ? 1 : 0;
     if (threadIdx.x == 0) {
       const float z = 1.0f + (float)(a.V - 1) * expf(-35.0f);
       a.leaf_tok[(size_t)c * dl1 * a.K] = a.pad;
