@@ -180,9 +180,12 @@ def ffn_bf16x6_run(tta, sd, device, make_gen, timed, warm, a, outs, raised, rows
     finally:
         os.environ.pop("TTX_FFN_BF16X6", None)
     ok = [i for i, o in enumerate(res) if o is not None]
+    rows_diff = sum(int((res[i] != outs[i]).any(dim=2).any(dim=1).sum()) for i in ok if i not in raised)
+    rows_cmp = sum(int(timed[i].shape[0]) for i in ok if i not in raised)
     out = {"value": sum(int(timed[i].shape[0]) for i in ok) / dt, "unit": "reactions/s",
            "tokens_identical_to_fp32_run": sorted(set(range(len(timed))) - set(ok)) == sorted(raised)
            and all(torch.equal(res[i], outs[i]) for i in ok),
+           "rows_differing_from_fp32_run": rows_diff, "rows_compared": rows_cmp,
            "what": "both FFN GEMMs (encoder and decoder) on v_mfma_f32_32x32x16_bf16: six partial products per fp32 product, operands "
                    "split in registers, fp32 accumulate; everything else as in the fp32 run.  Opt-in (TTX_FFN_BF16X6=1); the whole "
                    "-m gpu suite passes under it (every golden and oracle comparison token-identical)"}
