@@ -188,7 +188,7 @@ def test_config_c3_full_size_matches_oracle(tta):
     oracle = OracleTransformer(config_from_state(st, 8), st)
     src, _, _, _ = fixture_tokens()
     n_diff = n_total = 0
-    for rows in ([0, 2, 4, 6], [3, 5, 8, 9]):
+    for rows in ([0, 2, 4, 6],):          # one batch of C3's size in both draft modes (the CPU oracle takes ~40 s per mode)
         sel = src[rows]
         sel = sel[:, :int((sel != PAD).sum(1).max())]
         d, t = _compare_with_oracle(tta, native, oracle, sel, (5, 10, 7, 200), f"C3 rows {rows}")

@@ -87,7 +87,7 @@ def test_full_size_greedy_speculative_matches_oracle(tta, full_pair):
     native, oracle = full_pair
     src, tgt, c, _ = fixture_tokens()
     ref_greedy = GreedyOracle(oracle, 200, PAD, BOS, EOS).generate(src).numpy()[:, 0]
-    for N, D in ((3, 10), (1, 10), (7, 5), (23, 17)):
+    for N, D in ((3, 10), (23, 17)):       # the bench setting and the reference grid's widest (each costs a CPU oracle run)
         ref = GreedySpeculativeOracle(oracle, 200, D, N, PAD, BOS, EOS, c)
         exp = ref.generate(src)
         g = tta.TranslationInferenceGreedySpeculative(native, 200, D, N, PAD, BOS, EOS, c)
