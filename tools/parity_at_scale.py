@@ -73,11 +73,13 @@ def main():
     t0 = time.perf_counter()
     with torch.inference_mode():
         ref = []
-        for b in bs:
+        for k, b in enumerate(bs):
             try:
                 ref.append(GreedySpeculativeOracle(om, 200, 10, 3, PAD, BOS, EOS, C_TOK).generate(b))
             except Exception:
                 ref.append(None)
+            if (k + 1) % 8 == 0:
+                print(f"   oracle: {k + 1} / {len(bs)} batches, {time.perf_counter() - t0:.0f} s", flush=True)
     print(f"oracle: {sum(b.shape[0] for b in bs)} reactions in {time.perf_counter() - t0:.0f} s on {usable_cores()} threads", flush=True)
     outs = {}
     for name, flag in (("fp32 MFMA FFN", "0"), ("bf16x6 FFN", "1")):
