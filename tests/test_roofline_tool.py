@@ -1,0 +1,64 @@
+"""tools/roofline_from_trace.py on a small synthetic rocprofv3 trace: the roofline pass is found BY STREAM (the stream whose
+GEMM launch count equals bench.py's roofline.launches), its average launch duration and achieved TFLOP/s are recomputed from
+the trace, and the PMC passes are reduced to bytes per launch for exactly those launches."""
+import csv
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+TRACE_COLS = ["Kind", "Agent_Id", "Queue_Id", "Stream_Id", "Thread_Id", "Dispatch_Id", "Kernel_Id", "Kernel_Name", "Correlation_Id",
+              "Start_Timestamp", "End_Timestamp", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+              "Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"]
+
+
+def _trace(path, rows):
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=TRACE_COLS)
+        w.writeheader()
+        for i, (stream, name, start, dur) in enumerate(rows):
+            w.writerow({c: 0 for c in TRACE_COLS} | {"Kind": "KERNEL_DISPATCH", "Stream_Id": stream, "Dispatch_Id": i + 1, "Kernel_Name": name,
+                                                      "Start_Timestamp": start, "End_Timestamp": start + dur, "Workgroup_Size_X": 256,
+                                                      "Workgroup_Size_Y": 1, "Workgroup_Size_Z": 1, "Grid_Size_X": 1024, "Grid_Size_Y": 4,
+                                                      "Grid_Size_Z": 1})
+
+
+def _counters(path, rows, counter, value):
+    cols = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id", "Kernel_Name",
+            "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name",
+            "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=cols)
+        w.writeheader()
+        for i, (stream, name, start, dur) in enumerate(rows):
+            w.writerow({c: 0 for c in cols} | {"Dispatch_Id": i + 1, "Kernel_Name": name, "Counter_Name": counter, "Counter_Value": value})
+
+
+def test_roofline_pass_is_found_by_stream_and_reduced(tmp_path):
+    gemm = "void ttx::k_gemm24<4>(ttx::GemmArgs)"
+    rows = []
+    for i in range(10):                                   # timed region: stream 2, 10 GEMM launches of 50 us
+        rows.append((2, gemm, 1000 * i, 50_000))
+    for i in range(6):                                    # roofline pass: stream 7, 6 GEMM launches of 20 us + other kernels
+        rows.append((7, gemm, 100_000 + 1000 * i, 20_000))
+        rows.append((7, "ttx::k_finish_ln<4>(ttx::FinishArgs)", 200_000 + 1000 * i, 5_000))
+    _trace(tmp_path / "t.csv", rows)
+    _counters(tmp_path / "f_cc.csv", rows, "FETCH_SIZE", 1000.0)      # KB per launch
+    _counters(tmp_path / "w_cc.csv", rows, "WRITE_SIZE", 500.0)
+    line = {"value": 1.0, "unit": "reactions/s", "steps": 20, "warmup": 5, "config": {"workload": "x"},
+            "roofline": {"launches": 6, "avg_launch_us": 21.0, "achieved": 95.0, "unit": "TFLOP/s", "frac": 0.6, "peak": 157.3,
+                         "flops_per_launch": 2.0e9, "algorithmic_bytes_per_launch": 1.0e6, "event_pair_overhead_us": 4.7}}
+    (tmp_path / "b.jsonl").write_text("noise\n" + json.dumps(line) + "\n")
+    out_json = tmp_path / "pmc.json"
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "roofline_from_trace.py"), str(tmp_path / "t.csv"), str(tmp_path / "b.jsonl"),
+                        "--fetch", str(tmp_path / "f_cc.csv"), str(tmp_path / "t.csv"), "--write", str(tmp_path / "w_cc.csv"),
+                        str(tmp_path / "t.csv"), "--pmc-json", str(out_json), "--command", "test"],
+                       input='{"schedule": "rows", "inflight": 8}', capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "roofline pass = stream 7 (6 GEMM launches" in r.stdout
+    assert "average 20.00 us per launch" in r.stdout
+    assert "100.0 TFLOP/s" in r.stdout                    # 6 x 2 GFLOP / 120 us
+    entry = json.loads(out_json.read_text())[0]
+    assert entry["launches"] == 6 and entry["command_key"] == {"config": "c2", "steps": 20, "warmup": 5, "schedule": "rows", "inflight": 8}
+    assert abs(entry["bytes_per_launch"] - (2 * 1000 + 500) * 1024) < 1e-6
