@@ -105,7 +105,7 @@ def get_weights(train_steps: int, device: str, kind: str = "mit", layers: int = 
     (.weights_cache/, git-ignored), else trained here (set-up, untimed; `info` records which and how long it took)."""
     path = os.environ.get("TTX_WEIGHTS" if kind == "mit" else "TTX_WEIGHTS_50K") or f"/tmp/ttx_synth_{kind}_{train_steps}.pt"
     for cand in (path, str(ROOT / ".weights_cache" / f"synth_{kind}_{train_steps}.pt")):   # caches written by earlier runs
-        if os.path.exists(cand):
+        if os.path.exists(cand) and os.environ.get("TTX_NO_WEIGHTS_CACHE") != "1":             # =1: what a clean clone does
             if info is not None:
                 info.update(weights="cache", path=cand)
             return torch.load(cand, weights_only=True, map_location="cpu")
