@@ -264,3 +264,69 @@ def test_standard_beam_search_small_cases_match_oracle(tta):
         out = g.generate(sel.cuda()).cpu().numpy()
         np.testing.assert_array_equal(out, exp, err_msg=f"beam {beam} max_len {max_len}")
         assert g.model_calls_num == ref.model_calls_num
+
+
+def test_randomised_settings_match_oracle(tta):
+    """Forty random (rows, n_best, n_drafts, draft_len, max_len, draft mode) settings on the tiny model: every hypothesis and
+    the counters equal the oracle's; where the oracle's loop does not terminate within the guard, neither does the native one."""
+    from oracle.model import OracleTransformer, config_from_state
+    from oracle.spec_beam import BeamSearchSpeculativeOracle
+    st, cfg = tiny_state()
+    native = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    oracle = OracleTransformer(config_from_state(st, cfg["num_heads"]), st)
+    src, _, c, V = fixture_tokens()
+    rng = np.random.default_rng(20251004)
+    compared = guarded = 0
+    for trial in range(40):
+        rows = rng.choice(10, size=int(rng.integers(1, 6)), replace=False).tolist()
+        nbest = int(rng.choice([1, 2, 3, 5, 8]))
+        N = int(rng.choice([1, 2, 3, 7, 23]))
+        D = int(rng.choice([3, 5, 10, 17, 40]))
+        max_len = int(rng.choice([9, 30, 80, 150]))
+        smart = bool(rng.integers(0, 2))
+        sel = src[rows]
+        sel = sel[:, :int((sel != PAD).sum(1).max())]
+        ref = BeamSearchSpeculativeOracle(oracle, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=120)
+        g = tta.TranslationInferenceBeamSearchSpeculative(native, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=120)
+        try:
+            exp = ref.generate(sel).numpy()
+        except RuntimeError:
+            with pytest.raises(RuntimeError, match="max_steps"):
+                g.generate(sel.cuda())
+            guarded += 1
+            continue
+        out = g.generate(sel.cuda()).cpu().numpy()
+        label = (trial, rows, nbest, N, D, max_len, smart)
+        assert out.shape == exp.shape, label
+        np.testing.assert_array_equal(out, exp, err_msg=str(label))
+        assert (g.model_calls_num, g.accepted_tokens_num, g.produced_non_pad_tokens) == \
+               (ref.model_calls_num, ref.accepted_tokens_num, ref.produced_non_pad_tokens), label
+        compared += 1
+    print(f"randomised beam-speculative settings: {compared} compared, {guarded} hit the max_steps guard on both sides")
+    assert compared >= 25
+
+
+def test_randomised_standard_beam_search_matches_oracle(tta):
+    from oracle.model import OracleTransformer, config_from_state
+    from oracle.decoding import BeamSearchOracle
+    st, cfg = tiny_state()
+    native = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    oracle = OracleTransformer(config_from_state(st, cfg["num_heads"]), st)
+    src, _, _, _ = fixture_tokens()
+    rng = np.random.default_rng(7)
+    for trial in range(16):
+        rows = rng.choice(10, size=int(rng.integers(1, 7)), replace=False).tolist()
+        beam = int(rng.choice([1, 2, 3, 5, 10, 20]))
+        max_len = int(rng.choice([3, 12, 60, 150]))
+        sel = src[rows]
+        sel = sel[:, :int((sel != PAD).sum(1).max())]
+        ref = BeamSearchOracle(oracle, beam, max_len, PAD, BOS, EOS)
+        exp = ref.generate(sel).numpy()
+        g = tta.TranslationInferenceBeamSearch(native, beam, max_len, PAD, BOS, EOS)
+        out = g.generate(sel.cuda()).cpu().numpy()
+        assert out.shape == exp.shape, (trial, rows, beam, max_len)
+        # hypotheses up to their first EOS (after EOS the reference appends whatever wins the artificial PAD-35 row)
+        for b in range(out.shape[0]):
+            for k in range(out.shape[1]):
+                assert upto_eos(out[b, k]) == upto_eos(exp[b, k]), (trial, rows, beam, max_len, b, k)
+        assert g.model_calls_num == ref.model_calls_num and g.b_sz == ref.b_sz
