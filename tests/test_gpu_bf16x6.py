@@ -1,6 +1,6 @@
 """The opt-in FFN experiment (TTX_FFN_BF16X6=1: every product of the two FFN GEMMs formed from six bf16 MFMA partial products
 with fp32 accumulation, csrc/ttx_kernels.hip.h b6_split / b6_mma): the full-size reference-logits test must stay green under it (tolerance 1e-3, as for the fp32 path).  The switch is read when a session is created, so the selected tests run in a child pytest process.
-(The whole `-m gpu` suite passes under the switch as well — gpurun_out/gputest_b6.log of round 2; this keeps a fast subset.)"""
+(The whole `-m gpu` suite passes under the switch as well — profiles/r02_gputest_under_bf16x6.txt of round 2; this keeps a fast subset.)"""
 import os
 import subprocess
 import sys
@@ -18,7 +18,7 @@ def test_full_size_tests_stay_green_under_bf16x6_ffn():
     env = dict(os.environ, TTX_FFN_BF16X6="1")
     # the switch only applies where K per split is a multiple of 256 and one dimension is the FFN width, i.e. at the real layer
     # sizes (d = 256, FFN 2048): the full-size tests
-    # (the reference-logits test only: seconds; the whole suite was run under the switch by hand: gpurun_out/gputest_b6.log)
+    # (the reference-logits test only: seconds; the whole suite was run under the switch by hand: profiles/r02_gputest_under_bf16x6.txt)
     sel = ["tests/test_gpu_model.py::test_full_size_matches_reference"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", *sel], env=env, cwd=str(ROOT), capture_output=True,
                        text=True, timeout=900)
