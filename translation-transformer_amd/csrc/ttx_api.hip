@@ -279,7 +279,7 @@ struct ttx_session {
   Buf leaf_score, leaf_tok, leaf_cnt, beam_summary;
   // native beam-speculative loop
   Buf bs_cand_next, bs_len_next, bs_fin_next, bs_logp_next, bs_len, bs_fin, bs_active, bs_logp, bs_per_cand, bs_best_n, bs_best_slot,
-      bs_chosen, bs_parent, bs_parent_draft, bs_mark, bs_drafts_src, bs_cnt;
+      bs_chosen, bs_parent, bs_parent_draft, bs_mark, bs_drafts_src, bs_cnt, bs_hit;
   BeamHost* beam_host = nullptr;   // pinned + device-mapped, written by k_bs_publish
   // tree (beam) decoding
   Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of;
@@ -344,7 +344,7 @@ struct ttx_session {
                                  &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state, &leaf_score, &leaf_tok, &leaf_cnt,
                                  &beam_summary, &bs_cand_next, &bs_len_next, &bs_fin_next, &bs_logp_next, &bs_len, &bs_fin, &bs_active,
                                  &bs_logp, &bs_per_cand, &bs_best_n, &bs_best_slot, &bs_chosen, &bs_parent, &bs_parent_draft, &bs_mark,
-                                 &bs_drafts_src, &bs_cnt}) { b->owner_gen = &alloc_generation; all.push_back(b); } }
+                                 &bs_drafts_src, &bs_cnt, &bs_hit}) { b->owner_gen = &alloc_generation; all.push_back(b); } }
 };
 
 // Growing a workspace must not stall the other sessions' streams: hipFree waits for the whole device, so the old
@@ -1835,6 +1835,7 @@ static int beam_start(BeamJob& j, ttx_session* s, hipStream_t st, const int64_t*
   need(s->bs_cand_next, MC * j.gen_ld * 8); need(s->bs_len_next, MC * 4); need(s->bs_fin_next, MC); need(s->bs_logp_next, MC * 4);
   need(s->bs_len, MC * 4); need(s->bs_fin, MC); need(s->bs_active, MC); need(s->bs_logp, MC * 4); need(s->bs_per_cand, MC * 4);
   need(s->bs_best_n, MC * 4); need(s->bs_best_slot, MC * 4); need(s->bs_chosen, MC * std::max(j.D0, 1) * 8);
+  need(s->bs_hit, MC * (size_t)j.N * std::max(j.D0, 1));
   need(s->bs_parent, MC * 4); need(s->bs_parent_draft, MC * 4); need(s->bs_mark, MC * 4);
   need(s->bs_drafts_src, (size_t)B * (j.smart ? (size_t)j.n_lib * j.lib_ld : (size_t)j.N * j.D0) * 4);
   need(s->bs_cnt, sizeof(BeamCounters));
@@ -1945,19 +1946,30 @@ static int beam_enqueue_iter(const BeamJob& j, bool first, int cur) {
     } scope(s);
     TTX_TRY(run_step(s, st, k, std::min(j.p.max_len, ((j.width + 63) / 64) * 64)));
   }
-  BeamAcceptArgs aa{};
-  aa.logits = s->logits.as<float>(); aa.V = V; aa.finished = s->bs_fin.as<uint8_t>(); aa.slot_of = s->t_slot_of.as<int>();
-  aa.per_cand = s->bs_per_cand.as<int>(); aa.drafts32 = s->drafts.as<int>(); aa.cnt = s->bs_cnt.as<BeamCounters>();
-  aa.n_cand = j.n_cand; aa.N = j.N; aa.dl = dl; aa.K = j.K; aa.smart = j.smart ? 1 : 0; aa.nucleus = 0.9975f;
-  aa.best_n = s->bs_best_n.as<int>(); aa.best_slot = s->bs_best_slot.as<int>(); aa.chosen = s->bs_chosen.as<int64_t>();
-  hipLaunchKernelGGL(k_bs_accept, dim3(MC), dim3(BS_ACCEPT_THREADS), 0, st, aa);
-  HIP_TRY(hipGetLastError());
+  BeamHitsArgs ha{};
+  ha.logits = s->logits.as<float>(); ha.V = V; ha.finished = s->bs_fin.as<uint8_t>(); ha.slot_of = s->t_slot_of.as<int>();
+  ha.per_cand = s->bs_per_cand.as<int>(); ha.drafts32 = s->drafts.as<int>();
+  ha.n_cand = j.n_cand; ha.N = j.N; ha.dl = dl; ha.K = j.K; ha.nucleus = 0.9975f; ha.hit = s->bs_hit.as<uint8_t>();
   BeamLeaves2Args le{};
   le.logits = s->logits.as<float>(); le.V = V; le.finished = s->bs_fin.as<uint8_t>(); le.slot_of = s->t_slot_of.as<int>();
-  le.best_n = s->bs_best_n.as<int>(); le.best_slot = s->bs_best_slot.as<int>(); le.drafts32 = s->drafts.as<int>();
-  le.logp = s->bs_logp.as<float>(); le.n_cand = j.n_cand; le.N = j.N; le.dl = dl; le.K = j.K; le.bos = j.p.bos_token; le.pad = j.p.pad_token;
+  le.per_cand = s->bs_per_cand.as<int>(); le.drafts32 = s->drafts.as<int>(); le.logp = s->bs_logp.as<float>();
+  le.hit = s->bs_hit.as<uint8_t>(); le.cnt = s->bs_cnt.as<BeamCounters>();
+  le.n_cand = j.n_cand; le.N = j.N; le.dl = dl; le.K = j.K; le.bos = j.p.bos_token; le.pad = j.p.pad_token; le.smart = j.smart ? 1 : 0;
+  le.best_n = s->bs_best_n.as<int>(); le.best_slot = s->bs_best_slot.as<int>(); le.chosen = s->bs_chosen.as<int64_t>();
   le.leaf_score = s->leaf_score.as<float>(); le.leaf_tok = s->leaf_tok.as<int>(); le.leaf_cnt = s->leaf_cnt.as<int>();
-  hipLaunchKernelGGL(k_bs_leaves, dim3(MC), dim3(BS_LEAVES_THREADS), (size_t)2 * (dl + 1) * 4, st, le);
+  const dim3 hits_grid(MC, cdiv(std::max(j.N * dl, 1), BS_HITS_WAVES));
+  const size_t leaves_lds = (size_t)2 * (dl + 1) * 4;
+  // logits per lane the selection keeps in registers: the smallest of 4 / 8 / 16 that covers the vocabulary (same results)
+  if (V <= 256) {
+    if (dl > 0) hipLaunchKernelGGL(k_bs_hits<4>, hits_grid, dim3(BS_HITS_WAVES * 64), 0, st, ha);
+    hipLaunchKernelGGL(k_bs_leaves<4>, dim3(MC), dim3(BS_LEAVES_THREADS), leaves_lds, st, le);
+  } else if (V <= 512) {
+    if (dl > 0) hipLaunchKernelGGL(k_bs_hits<8>, hits_grid, dim3(BS_HITS_WAVES * 64), 0, st, ha);
+    hipLaunchKernelGGL(k_bs_leaves<8>, dim3(MC), dim3(BS_LEAVES_THREADS), leaves_lds, st, le);
+  } else {
+    if (dl > 0) hipLaunchKernelGGL(k_bs_hits<NUC_VPL>, hits_grid, dim3(BS_HITS_WAVES * 64), 0, st, ha);
+    hipLaunchKernelGGL(k_bs_leaves<NUC_VPL>, dim3(MC), dim3(BS_LEAVES_THREADS), leaves_lds, st, le);
+  }
   HIP_TRY(hipGetLastError());
   BeamSelectArgs<int> sa{s->leaf_score.as<float>(), s->leaf_tok.as<int>(), s->leaf_cnt.as<int>(), s->gen.as<int>(), j.gen_ld, j.gen_ld,
                          j.gen_ld, s->bs_len.as<int>(), s->bs_chosen.as<int64_t>(), s->bs_best_slot.as<int>(), s->bs_fin.as<uint8_t>(),

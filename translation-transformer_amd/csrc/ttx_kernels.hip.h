@@ -2444,6 +2444,54 @@ __device__ __forceinline__ void nucleus_select(const float* __restrict__ p, int 
   }
 }
 
+// The same selection with the result spread over the lanes instead of a register array indexed at run time (which the
+// compiler can only keep in scratch): lane r holds the rank-r entry.  Also hands back the softmax statistics (m, z)
+// computed exactly as above.
+// VPL = logits per lane held in registers (V <= 64 * VPL): the loops below run over VPL, so a small vocabulary does not pay
+// for 1 024 columns; the arithmetic (and so every result) is the same for any VPL that covers V.
+template <int VPL>
+__device__ __forceinline__ void topk_to_lanes(const float* __restrict__ p, int V, float nucleus, int n_best, int lane,
+                                              int& my_idx, float& my_val, int& n_kept, float& m_out, float& z_out) {
+  float v[VPL];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < V ? p[c] : -INFINITY;
+    m = fmaxf(m, v[i]);
+  }
+  m = wave_max(m);
+  float z = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) z += (lane + 64 * i < V) ? expf(v[i] - m) : 0.f;
+  z = wave_sum(z);
+  m_out = m; z_out = z;
+  n_kept = 0;
+  my_idx = -1; my_val = 0.f;
+  float above = 0.f;                        // softmax mass of the ranks already taken
+  for (int rank = 0; rank < n_best && rank < V; ++rank) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+      if (v[i] > best || (v[i] == best && lane + 64 * i < bi && v[i] != -INFINITY)) { best = v[i]; bi = lane + 64 * i; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (bi == 0x7fffffff) break;            // nothing finite left
+    if (rank != 0 && !(above < nucleus)) break;   // the mass above only grows: no later rank can be kept
+    if (lane == rank) { my_idx = bi; my_val = best; }
+    ++n_kept;
+    above += expf(best - m) / z;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+      if (lane + 64 * i == bi) v[i] = -INFINITY;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_nucleus(NucleusArgs a) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -2536,48 +2584,39 @@ __global__ __launch_bounds__(256) void k_ragged_topk(RaggedTopkArgs a) {
 //     in enumeration order), and the rows of the new candidates: root tokens, the kept draft tokens, the leaf token.
 // Core of the leaf enumeration for one candidate `c` (the whole workgroup): `rowp(p)` = logits row of position p along
 // the candidate's chosen draft, `chosen(p)` = its p-th draft token.
-template <class RowPtr, class Chosen>
+template <int VPL, class RowPtr, class Chosen>
 __device__ __forceinline__ void beam_leaves_core(int c, int nacc, float root, int dl, int V, int K, int bos, RowPtr rowp, Chosen chosen,
                                                  float* leaf_score, int* leaf_tok, int* leaf_cnt, float* lp_kept) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = (int)(blockDim.x >> 6);
   const int dl1 = dl + 1;
   float* run = lp_kept + dl1;                 // [dl+1] sequential prefix sums
-  // pass 1: per position softmax statistics, kept-token log-prob, and the surviving top-K (unsorted ranks)
+  // pass 1: per position softmax statistics, kept-token log-prob, and the surviving top-K in ascending token id
   for (int p = wave; p < dl1; p += n_waves) {
+    if (p > nacc) {
+      if (lane == 0) { lp_kept[p] = 0.f; leaf_cnt[(size_t)c * dl1 + p] = 0; }
+      continue;
+    }
     const float* row = rowp(p);
-    int ki[NUC_MAX_KEEP];
-    float kv[NUC_MAX_KEEP];
-    int nk = 0;
-    float m = -INFINITY, z = 0.f;
-    if (p <= nacc) {
-      nucleus_select(row, V, 20.0f, K, lane, ki, kv, nk);
-      float v[NUC_VPL];
-#pragma unroll
-      for (int i = 0; i < NUC_VPL; ++i) { const int col = lane + 64 * i; v[i] = col < V ? row[col] : -INFINITY; m = fmaxf(m, v[i]); }
-      m = wave_max(m);
-#pragma unroll
-      for (int i = 0; i < NUC_VPL; ++i) z += (lane + 64 * i < V) ? expf(v[i] - m) : 0.f;
-      z = wave_sum(z);
+    int my_idx, nk;
+    float my_val, m, z;
+    topk_to_lanes<VPL>(row, V, 20.0f, K, lane, my_idx, my_val, nk, m, z);     // lane r: the rank-r logit (nucleus 20 keeps every rank)
+    const int excl = (p < nacc) ? chosen(p) : ((p < dl) ? bos : -1);
+    // survivors (not the excluded token, not an exact-zero logit) go out in ascending token id: a survivor's place is the
+    // number of survivors with a smaller id
+    const bool valid = lane < nk && my_idx != excl && my_val != 0.0f;
+    const unsigned long long vm = __ballot(valid);
+    int pos = 0;
+    for (int j = 0; j < nk; ++j) {
+      const int oj = __shfl(my_idx, j, 64);
+      pos += (((vm >> j) & 1ull) && oj < my_idx) ? 1 : 0;
+    }
+    if (valid) {
+      leaf_tok[((size_t)c * dl1 + p) * K + pos] = my_idx;
+      leaf_score[((size_t)c * dl1 + p) * K + pos] = logf(expf(my_val - m) / z);     // log(softmax), as the reference writes it
     }
     if (lane == 0) {
-      int cnt = 0;
-      if (p <= nacc) {
-        const int excl = (p < nacc) ? chosen(p) : ((p < dl) ? bos : -1);
-        // ascending token id (insertion sort of <= 32 entries), dropping excluded tokens and exact-zero logits
-        for (int i = 0; i < nk; ++i) {
-          if (ki[i] == excl || kv[i] == 0.0f) continue;
-          int pos = cnt++;
-          float* ls = leaf_score + ((size_t)c * dl1 + p) * K;
-          int* lt = leaf_tok + ((size_t)c * dl1 + p) * K;
-          while (pos > 0 && lt[pos - 1] > ki[i]) { lt[pos] = lt[pos - 1]; ls[pos] = ls[pos - 1]; --pos; }
-          lt[pos] = ki[i];
-          ls[pos] = logf(expf(kv[i] - m) / z);         // log(softmax), as the reference writes it
-        }
-        lp_kept[p] = (p < nacc) ? logf(expf(row[chosen(p)] - m) / z) : 0.f;
-      } else {
-        lp_kept[p] = 0.f;
-      }
-      leaf_cnt[(size_t)c * dl1 + p] = cnt;
+      lp_kept[p] = (p < nacc) ? logf(expf(row[chosen(p)] - m) / z) : 0.f;
+      leaf_cnt[(size_t)c * dl1 + p] = __popcll(vm);
     }
   }
   __syncthreads();
@@ -2623,9 +2662,11 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
   __shared__ int s_bi[4];
   __shared__ int s_sel;
   const int nseg = a.beam * dl1;
-  if (threadIdx.x == 0) {
+  for (int sidx = threadIdx.x; sidx < nseg; sidx += blockDim.x) s_off[sidx] = a.leaf_cnt[(size_t)b * nseg + sidx];
+  __syncthreads();
+  if (threadIdx.x == 0) {                      // counts -> exclusive prefix, in LDS
     int acc = 0;
-    for (int sidx = 0; sidx < nseg; ++sidx) { s_off[sidx] = acc; acc += a.leaf_cnt[(size_t)b * nseg + sidx]; }
+    for (int sidx = 0; sidx < nseg; ++sidx) { const int n = s_off[sidx]; s_off[sidx] = acc; acc += n; }
     s_off[nseg] = acc;
   }
   __syncthreads();
@@ -2753,7 +2794,7 @@ __global__ __launch_bounds__(256) void k_tree_cache(TreeCacheArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Native beam-speculative loop (ttx_beam_speculative_generate; speculative_decoding.py:428-598 all drafts, :600-845 smart
-// drafts).  One iteration = k_bs_prep -> k_tree_cache -> k_bs_list -> the verify step (run_step) -> k_bs_accept ->
+// drafts).  One iteration = k_bs_prep -> k_tree_cache -> k_bs_list -> the verify step (run_step) -> k_bs_hits ->
 // k_bs_leaves -> k_beam_select<int> -> k_bs_publish.  The host knows every scalar of an iteration (candidate count, draft
 // length, logical width) from what the previous one published, so they travel as kernel arguments; only the list of
 // running candidates and the per-candidate choices live on the device.
@@ -2895,66 +2936,72 @@ __global__ __launch_bounds__(256) void k_bs_list(BeamListArgs a) {
   }
 }
 
-struct BeamAcceptArgs {
+struct BeamHitsArgs {
   const float* logits; int V;                        // the step's logits, [n_active * RPS, V]
   const uint8_t* finished; const int* slot_of; const int* per_cand; const int* drafts32;
-  const BeamCounters* cnt;
-  int n_cand, N, dl, K, smart;
+  int n_cand, N, dl, K;
   float nucleus;
-  int* best_n; int* best_slot; int64_t* chosen;      // [max_cand], [max_cand], [max_cand, dl]
+  uint8_t* hit;                                      // [max_cand, N * dl]: draft token inside the kept set of its position?
 };
 
-// One workgroup (16 waves) per candidate.  Accepted length of each of its drafts = leading draft tokens that are among the
-// <= K tokens inside the nucleus of their position (:539-548, :847-869; finished candidates see the artificial "35 on PAD"
-// logits, under which no draft token survives).  Every (draft, position) pair is tested by a wave of its own — the positions
-// are independent, only the count of LEADING hits matters — then the best draft exactly as the reference's topk(1) picks it
-// among equal counts (ttx_select.h): over the N drafts, or in smart mode over the table padded with -1 to the longest group.
-constexpr int BS_ACCEPT_THREADS = 1024;
-constexpr int BS_MAX_PAIRS = BS_MAX_SLOTS * 32;      // LDS hit flags: the kernel falls back to a per-draft walk beyond this
-__global__ __launch_bounds__(BS_ACCEPT_THREADS) void k_bs_accept(BeamAcceptArgs a) {
+// Acceptance test of every (draft, position) pair of every running candidate, one wave per pair, spread over the whole
+// chip (grid = candidates x groups of four pairs): is the draft token among the <= K tokens inside the nucleus of its
+// position (:539-548, :847-869)?  The positions are independent — only the count of LEADING hits matters, and k_bs_leaves
+// takes it from these flags.  (One workgroup per candidate doing all its pairs kept 20-80 CUs busy for 40-60 us.)
+constexpr int BS_HITS_WAVES = 4;
+template <int VPL>
+__global__ __launch_bounds__(BS_HITS_WAVES * 64) void k_bs_hits(BeamHitsArgs a) {
+  const int c = blockIdx.x;
+  if (c >= a.n_cand || a.finished[c]) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = blockIdx.y * BS_HITS_WAVES + wave;
+  if (p >= a.per_cand[c] * a.dl) return;
+  const int i = p / a.dl, j = p % a.dl;
+  const int srow = (j == 0) ? 0 : 1 + i * a.dl + (j - 1);
+  const float* row = a.logits + ((size_t)a.slot_of[c] * step_rps(a.N, a.dl) + srow) * a.V;
+  const int tok = a.drafts32[((size_t)c * a.N + i) * a.dl + j];
+  int my_idx, nk;
+  float my_val, m, z;
+  topk_to_lanes<VPL>(row, a.V, a.nucleus, a.K, lane, my_idx, my_val, nk, m, z);
+  const bool h = __ballot(lane < nk && my_idx == tok) != 0ull;
+  if (lane == 0) a.hit[(size_t)c * a.N * a.dl + p] = h ? 1 : 0;
+}
+
+struct BeamLeaves2Args {
+  const float* logits; int V;
+  const uint8_t* finished; const int* slot_of; const int* per_cand; const int* drafts32; const float* logp;
+  const uint8_t* hit; const BeamCounters* cnt;
+  int n_cand, N, dl, K, bos, pad, smart;
+  int* best_n; int* best_slot; int64_t* chosen;      // [max_cand], [max_cand], [max_cand, dl]
+  float* leaf_score; int* leaf_tok; int* leaf_cnt;
+};
+
+// One workgroup per candidate.  (1) Accepted length of each of its drafts = leading hits of k_bs_hits (finished candidates
+// see the artificial "35 on PAD" logits, under which no draft token survives), then the best draft exactly as the
+// reference's topk(1) picks it among equal counts (ttx_select.h): over the N drafts, or in smart mode over the table padded
+// with -1 to the longest group.  (2) `sample` (:294-400) on the step's own logits rows along that draft.  A finished
+// candidate has exactly one leaf: PAD at position 0 with log-softmax(35 on PAD, 0 elsewhere)[PAD] =
+// log(1 / (1 + (V-1) e^-35)), which is 0 in fp32.
+constexpr int BS_LEAVES_THREADS = 768;        // a wave per position of the chosen draft up to draft_len 11
+template <int VPL>
+__global__ __launch_bounds__(BS_LEAVES_THREADS) void k_bs_leaves(BeamLeaves2Args a) {
+  extern __shared__ float lp_kept[];
   __shared__ int s_nok[BS_MAX_SLOTS];
   __shared__ long long s_v[BS_MAX_SLOTS];
   __shared__ int s_ix[BS_MAX_SLOTS];
   __shared__ int s_best;
-  __shared__ unsigned char s_hit[BS_MAX_PAIRS];
   const int c = blockIdx.x;
   if (c >= a.n_cand) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+  const int dl1 = a.dl + 1;
   const int pc = a.per_cand[c];
-  const int RPS = step_rps(a.N, a.dl);
   const bool fin = a.finished[c] != 0;
-  const float* base = fin ? nullptr : a.logits + (size_t)a.slot_of[c] * RPS * a.V;
-  auto hit_at = [&](int i, int j) -> bool {          // is token j of draft i inside the kept set of its position?
-    int ki[NUC_MAX_KEEP];
-    float kv[NUC_MAX_KEEP];
-    int nk;
-    const int srow = (j == 0) ? 0 : 1 + i * a.dl + (j - 1);
-    nucleus_select(base + (size_t)srow * a.V, a.V, a.nucleus, a.K, lane, ki, kv, nk);
-    const int tok = a.drafts32[((size_t)c * a.N + i) * a.dl + j];
-    bool hit = false;
-    for (int q = 0; q < nk; ++q) hit |= (ki[q] == tok);
-    return hit;
-  };
-  const int pairs = pc * a.dl;
-  if (fin) {
-    for (int i = threadIdx.x; i < pc; i += blockDim.x) s_nok[i] = 0;
-  } else if (pairs <= BS_MAX_PAIRS) {
-    for (int p = wave; p < pairs; p += n_waves) {
-      const bool h = hit_at(p / a.dl, p % a.dl);
-      if (lane == 0) s_hit[p] = h ? 1 : 0;
+  for (int i = threadIdx.x; i < pc; i += blockDim.x) {
+    int ok = 0;
+    if (!fin) {
+      const uint8_t* h = a.hit + (size_t)c * a.N * a.dl + (size_t)i * a.dl;
+      while (ok < a.dl && h[ok]) ++ok;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < pc; i += blockDim.x) {
-      int ok = 0;
-      while (ok < a.dl && s_hit[i * a.dl + ok]) ++ok;
-      s_nok[i] = ok;
-    }
-  } else {
-    for (int i = wave; i < pc; i += n_waves) {        // very long drafts: walk each draft until its first miss
-      int ok = 0;
-      while (ok < a.dl && hit_at(i, ok)) ++ok;
-      if (lane == 0) s_nok[i] = ok;
-    }
+    s_nok[i] = ok;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2968,24 +3015,7 @@ __global__ __launch_bounds__(BS_ACCEPT_THREADS) void k_bs_accept(BeamAcceptArgs 
   __syncthreads();
   const int best = s_best;
   for (int j = threadIdx.x; j < a.dl; j += blockDim.x) a.chosen[(size_t)c * a.dl + j] = (int64_t)a.drafts32[((size_t)c * a.N + best) * a.dl + j];
-}
-
-struct BeamLeaves2Args {
-  const float* logits; int V;
-  const uint8_t* finished; const int* slot_of; const int* best_n; const int* best_slot; const int* drafts32; const float* logp;
-  int n_cand, N, dl, K, bos, pad;
-  float* leaf_score; int* leaf_tok; int* leaf_cnt;
-};
-
-// `sample` (:294-400) on the step's own logits rows.  A finished candidate has exactly one leaf: PAD at position 0 with
-// log-softmax(35 on PAD, 0 elsewhere)[PAD] = log(1 / (1 + (V-1) e^-35)), which is 0 in fp32.
-constexpr int BS_LEAVES_THREADS = 256;        // four waves share the positions of the chosen draft (16 waves measured slower: 122 vs 70 us)
-__global__ __launch_bounds__(BS_LEAVES_THREADS) void k_bs_leaves(BeamLeaves2Args a) {
-  extern __shared__ float lp_kept[];
-  const int c = blockIdx.x;
-  if (c >= a.n_cand) return;
-  const int dl1 = a.dl + 1;
-  if (a.finished[c]) {
+  if (fin) {
     for (int p = threadIdx.x; p < dl1; p += blockDim.x) a.leaf_cnt[(size_t)c * dl1 + p] = (p == 0) ? 1 : 0;
     if (threadIdx.x == 0) {
       const float z = 1.0f + (float)(a.V - 1) * expf(-35.0f);
@@ -2995,13 +3025,12 @@ __global__ __launch_bounds__(BS_LEAVES_THREADS) void k_bs_leaves(BeamLeaves2Args
     return;
   }
   const int RPS = step_rps(a.N, a.dl);
-  const int best = a.best_slot[c];
   const float* base = a.logits + (size_t)a.slot_of[c] * RPS * a.V;
   const int* dr = a.drafts32 + ((size_t)c * a.N + best) * a.dl;
-  beam_leaves_core(c, a.best_n[c], a.logp[c], a.dl, a.V, a.K, a.bos,
-                   [&](int p) { return base + (size_t)((p == 0) ? 0 : 1 + best * a.dl + (p - 1)) * a.V; },
-                   [&](int p) { return dr[p]; },
-                   a.leaf_score, a.leaf_tok, a.leaf_cnt, lp_kept);
+  beam_leaves_core<VPL>(c, s_nok[best], a.logp[c], a.dl, a.V, a.K, a.bos,
+                        [&](int p) { return base + (size_t)((p == 0) ? 0 : 1 + best * a.dl + (p - 1)) * a.V; },
+                        [&](int p) { return dr[p]; },
+                        a.leaf_score, a.leaf_tok, a.leaf_cnt, lp_kept);
 }
 
 // Last kernel of an iteration: the selection summary and the iteration count go to the pinned words the host polls (the
