@@ -2658,9 +2658,6 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
   float* sc = sh;
   int* code = reinterpret_cast<int*>(sh + L);  // enumeration rank of each strided entry (for tie-breaking) or -1
   __shared__ int s_off[1024];                  // exclusive prefix of leaf counts over (candidate, position) of this source
-  __shared__ float s_best[4];
-  __shared__ int s_bi[4];
-  __shared__ int s_sel;
   const int nseg = a.beam * dl1;
   for (int sidx = threadIdx.x; sidx < nseg; sidx += blockDim.x) s_off[sidx] = a.leaf_cnt[(size_t)b * nseg + sidx];
   __syncthreads();
@@ -2680,38 +2677,54 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
   if (s_off[nseg] < a.K) { if (threadIdx.x == 0) a.summary[4] = 1; return; }   // the reference asserts len >= k
   __shared__ int s_win[NUC_MAX_KEEP];          // strided entry of the r-th best leaf
   __shared__ float s_wsc[NUC_MAX_KEEP];
-  for (int r = 0; r < a.K; ++r) {
-    float best = -INFINITY;
-    int bc = 0x7fffffff, be = -1;
-    for (int e = threadIdx.x; e < L; e += blockDim.x) {
-      const float v = sc[e];
-      const int cd = code[e];
-      if (cd != 0x7fffffff && (v > best || (v == best && cd < bc))) { best = v; bc = cd; be = e; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oc = __shfl_xor(bc, o, 64);
-      const int oe = __shfl_xor(be, o, 64);
-      if (oc != 0x7fffffff && (ov > best || (ov == best && oc < bc) || bc == 0x7fffffff)) { best = ov; bc = oc; be = oe; }
-    }
-    if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = best; s_bi[threadIdx.x >> 6] = be; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int sel = s_bi[0];
-      float bv = s_best[0];
-      for (int w = 1; w < 4; ++w) {
-        const int e2 = s_bi[w];
-        if (e2 < 0) continue;
-        if (sel < 0 || s_best[w] > bv || (s_best[w] == bv && code[e2] < code[sel])) { sel = e2; bv = s_best[w]; }
+  // Order: higher score first, equal scores by enumeration code (codes are unique).  Two levels, one barrier: every wave
+  // takes the K best of ITS quarter of the entries in K rounds of wave-wide arg-max (no workgroup barrier inside the
+  // rounds), then the <= 4K survivors are ranked against each other by counting — the K best overall are among them.
+  __shared__ float s_csc[4 * NUC_MAX_KEEP];
+  __shared__ int s_ccode[4 * NUC_MAX_KEEP];
+  __shared__ int s_ce[4 * NUC_MAX_KEEP];
+  {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per_wave = (L + 3) / 4, lo = wave * per_wave, hi = min(L, lo + per_wave);
+    for (int r = 0; r < a.K; ++r) {
+      float best = -INFINITY;
+      int bc = 0x7fffffff, be = -1;
+      for (int e = lo + lane; e < hi; e += 64) {
+        const float v = sc[e];
+        const int cd = code[e];
+        if (cd != 0x7fffffff && (be < 0 || v > best || (v == best && cd < bc))) { best = v; bc = cd; be = e; }
       }
-      s_win[r] = sel;
-      s_wsc[r] = sc[sel];
-      sc[sel] = -INFINITY;                     // taken
-      code[sel] = 0x7fffffff;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oc = __shfl_xor(bc, o, 64);
+        const int oe = __shfl_xor(be, o, 64);
+        if (oe >= 0 && (be < 0 || ov > best || (ov == best && oc < bc))) { best = ov; bc = oc; be = oe; }
+      }
+      if (lane == 0) {
+        s_csc[wave * a.K + r] = best; s_ccode[wave * a.K + r] = bc; s_ce[wave * a.K + r] = be;
+        if (be >= 0) code[be] = 0x7fffffff;      // taken (the score stays: it is read again below)
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();
   }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 4 * a.K; t += blockDim.x) {
+    const int e = s_ce[t];
+    if (e < 0) continue;
+    const float v = s_csc[t];
+    const int cd = s_ccode[t];
+    int rank = 0;
+    for (int u = 0; u < 4 * a.K; ++u) {
+      if (s_ce[u] < 0) continue;
+      const float ov = s_csc[u];
+      rank += (ov > v || (ov == v && s_ccode[u] < cd)) ? 1 : 0;
+    }
+    if (rank < a.K) { s_win[rank] = e; s_wsc[rank] = v; }
+  }
+  __syncthreads();
   // the K new rows, all at once: root tokens, the kept draft tokens, the leaf token
   for (int e = threadIdx.x; e < a.K * a.width; e += blockDim.x) {
     const int r = e / a.width, col = e - r * a.width;
