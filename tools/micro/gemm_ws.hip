@@ -31,10 +31,16 @@ struct GemmArgs {            // as in ttx_kernels.hip.h
 #include "gemm_ws_body.hip.h"
 using namespace ttx;
 
-__global__ __launch_bounds__(256, 2) void k_ws(GemmArgs a) {
+#ifndef WS_WAVES
+#define WS_WAVES 4
+#endif
+#ifndef WS_DEEP
+#define WS_DEEP true
+#endif
+__global__ __launch_bounds__(64 * WS_WAVES, 2) void k_ws(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int M = a.m_ptr ? *a.m_ptr : a.M;
-  gws_body(a, M, blockIdx.x, gridDim.x, smem);
+  gws_body<WS_WAVES, WS_DEEP>(a, M, blockIdx.x, gridDim.x, smem);
 }
 
 // canonical order, nothing else: one wave per 32x32 tile, operands straight from global memory
@@ -98,9 +104,9 @@ int main(int argc, char** argv) {
         k_ref<<<dim3(N / 32, (M + 31) / 32), 64>>>(a);
         a.Y = Y1;
         const int n_strips = N / 64, n_rb = (M + 31) / 32;
-        const int n_grp = std::max(1, std::min((n_rb + 3) / 4, 512 / n_strips));
+        const int n_grp = std::max(1, std::min((n_rb + WS_WAVES - 1) / WS_WAVES, 512 / n_strips));
         const int n_wgs = n_strips * n_grp;
-        k_ws<<<n_wgs, 256, GWS_SMEM_FLOATS * 4>>>(a);
+        k_ws<<<n_wgs, 64 * WS_WAVES, GWS_SMEM_FLOATS * 4>>>(a);
         CK(hipDeviceSynchronize());
         std::vector<float> h0((size_t)M * N), h1((size_t)M * N);
         CK(hipMemcpy(h0.data(), Y0, h0.size() * 4, hipMemcpyDeviceToHost));
@@ -109,7 +115,7 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < h0.size(); ++i) bad += std::memcmp(&h0[i], &h1[i], 4) != 0;
         const int iters = 50;
         CK(hipEventRecord(e0));
-        for (int i = 0; i < iters; ++i) k_ws<<<n_wgs, 256, GWS_SMEM_FLOATS * 4>>>(a);
+        for (int i = 0; i < iters; ++i) k_ws<<<n_wgs, 64 * WS_WAVES, GWS_SMEM_FLOATS * 4>>>(a);
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));

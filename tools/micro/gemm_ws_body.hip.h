@@ -25,6 +25,7 @@ typedef float gws_f4 __attribute__((ext_vector_type(4)));
 
 // `lin` = linear index of this workgroup among the `n_wgs` (256-thread) workgroups of the launch that take part.
 // Requires K == 256 == k_per_split, N % 64 == 0, ldx/ldw % 4 == 0 and n_wgs >= N / 64.
+template <int WAVES = 4, bool DEEP = true>
 __device__ __forceinline__ void gws_body(const GemmArgs& a, const int M, const int lin, const int n_wgs, float* wl) {
   const int n_strips = a.N >> 6;
   const int n_grp = n_wgs / n_strips;                   // workgroups per strip
@@ -43,12 +44,12 @@ __device__ __forceinline__ void gws_body(const GemmArgs& a, const int M, const i
   }
 #endif
   const int n_rb = (M + 31) >> 5;                       // 32-row blocks
-  if (grp * 4 >= n_rb) return;                          // nothing for any wave of this workgroup (uniform)
+  if (grp * WAVES >= n_rb) return;                      // nothing for any wave of this workgroup (uniform)
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
   const int n0 = strip * GWS_BN;
-  const int stride = n_grp * 4;
-  int rb = grp * 4 + wave;
+  const int stride = n_grp * WAVES;
+  int rb = grp * WAVES + wave;
 
   // The four 64-k chunks of a block live in four fixed register buffers; the moment a chunk has been consumed its buffer is
   // refilled with the same chunk of the wave's NEXT block, so every load is three chunks (about 10 us) ahead of its use —
@@ -66,14 +67,15 @@ __device__ __forceinline__ void gws_body(const GemmArgs& a, const int M, const i
     for (int g = 0; g < 8; ++g) c[g] = *reinterpret_cast<const gws_f4*>(xp + k0 + 8 * g);
   };
   const float* xp = a.X + (size_t)min(min(rb, n_rb - 1) * 32 + r, M - 1) * a.ldx + 4 * h;   // idle waves read a valid block
-  xload(c0, xp, 0); xload(c1, xp, 64); xload(c2, xp, 128); xload(c3, xp, 192);
+  xload(c0, xp, 0);
+  if constexpr (DEEP) { xload(c1, xp, 64); xload(c2, xp, 128); xload(c3, xp, 192); }
 
   // the strip: 64 columns x 64 float4, consecutive threads along k (coalesced), 16 float4 per thread
   {
     const float* wsrc = a.W + (size_t)n0 * a.ldw;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = t + 256 * i;
+    for (int i = 0; i < 64 / WAVES; ++i) {
+      const int idx = t + 64 * WAVES * i;
       const int col = idx >> 6, k4 = idx & 63;
       *reinterpret_cast<gws_f4*>(&wl[col * GWS_LDW + 4 * k4]) = *reinterpret_cast<const gws_f4*>(wsrc + (size_t)col * a.ldw + 4 * k4);
     }
@@ -115,6 +117,36 @@ __device__ __forceinline__ void gws_body(const GemmArgs& a, const int M, const i
     }
   };
 
+  if constexpr (!DEEP) {
+    // first version of the experiment: two buffers, one chunk ahead, stores straight after the last chunk (fewer registers:
+    // four waves per SIMD fit)
+    for (; rb < n_rb; rb += stride) {
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+      const int m0 = rb * 32;
+      const float* xc = a.X + (size_t)min(m0 + r, M - 1) * a.ldx + 4 * h;
+      if (rb == grp * WAVES + wave) { /* c0 holds chunk 0 of the first block already */ } else xload(c0, xc, 0);
+      xload(c1, xc, 64);
+      chunk_mma(acc0, acc1, c0, 0);
+      xload(c0, xc, 128);
+      chunk_mma(acc0, acc1, c1, 64);
+      xload(c1, xc, 192);
+      chunk_mma(acc0, acc1, c0, 128);
+      chunk_mma(acc0, acc1, c1, 192);
+      float* yp = Y + (size_t)(m0 + 4 * h) * a.ldy + n0 + r;
+      const int rows_left = M - (m0 + 4 * h);
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int dr = (v & 3) + 8 * (v >> 2);
+        if (dr < rows_left) {
+          yp[(size_t)dr * a.ldy] = fmaxf(acc0[v] + bv0, lo);
+          yp[(size_t)dr * a.ldy + 32] = fmaxf(acc1[v] + bv1, lo);
+        }
+      }
+    }
+    return;
+  }
   // Rows this launch may write: with a device-side row count the buffers hold a.M rows (the capacity), so a block that
   // starts below the live count is stored whole when it fits the capacity — rows past the live count are dead to every
   // consumer.  Only such blocks run in the pipelined loop: a second, predicated store path inside it would make the
