@@ -330,3 +330,60 @@ def test_randomised_standard_beam_search_matches_oracle(tta):
             for k in range(out.shape[1]):
                 assert upto_eos(out[b, k]) == upto_eos(exp[b, k]), (trial, rows, beam, max_len, b, k)
         assert g.model_calls_num == ref.model_calls_num and g.b_sz == ref.b_sz
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [300, 700])
+def test_wide_vocabularies_match_oracle(tta, V):
+    """Vocabularies beyond 256 and beyond 512 tokens: the selection kernels keep ceil(V/64) logits per lane and are compiled
+    for 4, 8 and 16 of them (the bench and the goldens only reach 4).  Seeded random 2+2 weights (d=64, 2 heads): the
+    model rarely ends a row, so max_len is small; beam-speculative (both draft modes), standard beam and greedy
+    speculative against the oracle, every hypothesis."""
+    from oracle.model import OracleTransformer, config_from_state
+    from oracle.spec_beam import BeamSearchSpeculativeOracle
+    from oracle.decoding import BeamSearchOracle, GreedySpeculativeOracle
+    from util_models import seeded_weights, state_shapes
+    w = seeded_weights(state_shapes(V, 64, 128, 2, 2), 4242 + V)
+    w["tgt_token_featurizer.embedding.weight"] = w["src_token_featurizer.embedding.weight"]
+    st = {k: torch.from_numpy(v) for k, v in w.items()}
+    native = tta.NativeTransformer(st, 2, PAD, device=0)
+    oracle = OracleTransformer(config_from_state(st, 2), st)
+    rng = np.random.default_rng(V)
+    c_tok = 4
+    compared = 0
+    for trial in range(4):
+        B, Ls = int(rng.integers(1, 5)), int(rng.integers(8, 30))
+        src = torch.from_numpy(rng.integers(4, V, size=(B, Ls)).astype(np.int64))
+        src[:, 0] = BOS
+        for b in range(B):
+            n = int(rng.integers(6, Ls + 1))
+            src[b, n - 1] = EOS
+            src[b, n:] = PAD
+        src = src[:, :int((src != PAD).sum(1).max())]
+        nbest, N, D, max_len = int(rng.choice([2, 5, 10])), int(rng.choice([1, 3])), int(rng.choice([3, 6])), int(rng.choice([12, 25]))
+        for smart in (False, True):
+            ref = BeamSearchSpeculativeOracle(oracle, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c_tok, max_steps=80)
+            g = tta.TranslationInferenceBeamSearchSpeculative(native, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c_tok, max_steps=80)
+            try:
+                exp = ref.generate(src).numpy()
+            except (RuntimeError, AssertionError):
+                continue
+            out = g.generate(src.cuda()).cpu().numpy()
+            np.testing.assert_array_equal(out, exp, err_msg=str((V, trial, smart, nbest, N, D, max_len)))
+            assert g.model_calls_num == ref.model_calls_num and g.accepted_tokens_num == ref.accepted_tokens_num
+            compared += 1
+        beam = int(rng.choice([1, 3, 8]))
+        exp = BeamSearchOracle(oracle, beam, max_len, PAD, BOS, EOS).generate(src).numpy()
+        out = tta.TranslationInferenceBeamSearch(native, beam, max_len, PAD, BOS, EOS).generate(src.cuda()).cpu().numpy()
+        assert out.shape == exp.shape
+        for b in range(out.shape[0]):
+            for k in range(out.shape[1]):
+                assert upto_eos(out[b, k]) == upto_eos(exp[b, k]), (V, trial, "beam", b, k)
+        gs_ref = GreedySpeculativeOracle(oracle, max_len, D, N, PAD, BOS, EOS, c_tok)
+        gs = tta.TranslationInferenceGreedySpeculative(native, max_len, D, N, PAD, BOS, EOS, c_tok)
+        try:
+            exp = gs_ref.generate(src).numpy()
+        except (RuntimeError, AssertionError):      # a random model may emit PAD/BOS before EOS: the reference's scatter raises
+            continue
+        np.testing.assert_array_equal(gs.generate(src.cuda()).cpu().numpy(), exp)
+    assert compared >= 4
