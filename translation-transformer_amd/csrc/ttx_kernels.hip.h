@@ -2574,7 +2574,7 @@ __global__ __launch_bounds__(256) void k_ragged_topk(RaggedTopkArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Beam-speculative candidate expansion (SURVEY.md §2.3 K12 + K14; speculative_decoding.py:294-400 `sample`, :573-598).
-//   k_beam_leaves: one workgroup per candidate.  For every position p <= n_accepted of the candidate's chosen draft: the
+//   leaf enumeration (beam_leaves_core, called by k_bs_leaves): one workgroup per candidate.  For every position p <= n_accepted of the candidate's chosen draft: the
 //     n_best largest logits (nucleus >= 1 mode) minus the accepted draft token (positions < n_accepted), minus <BOS> at
 //     the first rejected position, minus logits that are exactly 0 — each survivor is a leaf "keep p draft tokens, then
 //     this token".  Leaf score = log-prob of the root + log-softmax of the kept tokens summed in position order (fp32,
