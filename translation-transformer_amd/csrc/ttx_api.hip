@@ -333,6 +333,8 @@ struct ttx_session {
   double prof_empty_pair_ms = -1;
   bool host_timing = false;
   double host_launch_us = 0;
+  long long host_captures = 0;      // TTX_HOST_TIMING: beam iteration graphs captured on this session and the host time they took
+  double host_capture_us = 0;
   long long host_launches = 0;
   long long prof_launches = 0;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
@@ -430,6 +432,9 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
   if (s->host_timing && s->host_launches)
     fprintf(stderr, "[ttx host timing] hipGraphLaunch: %lld launches, %.1f us each\n", s->host_launches,
             s->host_launch_us / (double)s->host_launches);
+  if (s->host_timing && s->host_captures)
+    fprintf(stderr, "[ttx host timing] beam iteration graphs captured: %lld, %.1f us each\n", s->host_captures,
+            s->host_capture_us / (double)s->host_captures);
   if (s->dead) {        // hipFree / hipDeviceSynchronize would wait for the stuck stream, and a late kernel may still write
     delete s;           // the mapped host words: leak workspaces, pinned memory, graphs and events of a hung session
     return;
@@ -2016,6 +2021,7 @@ static int beam_launch_iter(BeamJob& j) {
       if (it == s->beam_graphs.end()) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
+        const auto cap0 = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamBeginCapture(j.st, hipStreamCaptureModeThreadLocal));
         rc = beam_enqueue_iter(j, first, cur);
         hipError_t e = hipStreamEndCapture(j.st, &graph);
@@ -2026,6 +2032,8 @@ static int beam_launch_iter(BeamJob& j) {
         if (e != hipSuccess) return fail(TTX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
         if (s->beam_graphs.size() > 256) s->drop_graphs();
         it = s->beam_graphs.emplace(key, exec).first;
+        s->host_captures += 1;
+        s->host_capture_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - cap0).count();
       }
       HIP_TRY(hipGraphLaunch(it->second, j.st));
     }
