@@ -11,13 +11,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="$ROOT/bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline"
 echo "[1/4] kernel trace, timed-only"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_timed -o t --output-format csv -- python3 $ROOT/bench.py --gpus 1 --steps $STEPS --warmup $WARM --timed-only > $OUT/${TAG}_timed.jsonl 2> $OUT/${TAG}_timed.err || exit 1
+timeout -k 10 ${TRACE_TIMEOUT:-300} rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_timed -o t --output-format csv -- python3 $ROOT/bench.py --gpus 1 --steps $STEPS --warmup $WARM --timed-only > $OUT/${TAG}_timed.jsonl 2> $OUT/${TAG}_timed.err || exit 1
 echo "[2/4] kernel trace, with the roofline pass"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_full -o f --output-format csv -- python3 $CMD > $OUT/${TAG}_full.jsonl 2> $OUT/${TAG}_full.err || exit 1
+timeout -k 10 ${TRACE_TIMEOUT:-300} rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_full -o f --output-format csv -- python3 $CMD > $OUT/${TAG}_full.jsonl 2> $OUT/${TAG}_full.err || exit 1
 echo "[3/4] PMC FETCH_SIZE"
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o p --output-format csv -- python3 $CMD > $OUT/${TAG}_fetch.jsonl 2> $OUT/${TAG}_fetch.err || exit 1
+timeout -k 10 ${PMC_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o p --output-format csv -- python3 $CMD > $OUT/${TAG}_fetch.jsonl 2> $OUT/${TAG}_fetch.err || exit 1
 echo "[4/4] PMC WRITE_SIZE"
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o p --output-format csv -- python3 $CMD > $OUT/${TAG}_write.jsonl 2> $OUT/${TAG}_write.err || exit 1
+timeout -k 10 ${PMC_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o p --output-format csv -- python3 $CMD > $OUT/${TAG}_write.jsonl 2> $OUT/${TAG}_write.err || exit 1
 ls -la $OUT/${TAG}_*/ | head -40
 # summaries (small) next to the raw output; the raw CSVs are too large to travel back (64 MiB cap) and are removed
 S=$OUT/${TAG}_summary
