@@ -2,17 +2,17 @@
 """Would a split-bf16 FFN change any token?  CPU experiment for DESIGN.md §8 item 1: the oracle model with its two FFN products
 computed from bf16 pieces (x = hi + mid + lo, bf16 x bf16 products exact in fp32, fp32 accumulation per partial product — what
 six (or three) bf16 MFMAs per fp32 MFMA would compute), run through every golden generator case; reports how many golden
-hypotheses change.  Test infrastructure only (imports oracle/).  Usage: python tools/bf16_split_tokens.py [3|6]"""
+hypotheses change.  Test infrastructure only (imports oracle/).  Usage: python tests/tools/bf16_split_tokens.py [3|6]"""
 import sys
 from pathlib import Path
 
-import numpy as np
+
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 from oracle.model import OracleTransformer, config_from_state  # noqa: E402
-from oracle.decoding import GreedyOracle, GreedySpeculativeOracle, BeamSearchOracle  # noqa: E402
+from oracle.decoding import GreedyOracle, BeamSearchOracle  # noqa: E402
 from oracle.spec_beam import BeamSearchSpeculativeOracle  # noqa: E402
 from util_models import load_npz, fixture_tokens, tiny_state, upto_eos, PAD, BOS, EOS  # noqa: E402
 

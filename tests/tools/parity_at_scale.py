@@ -4,7 +4,7 @@ through the CPU oracle (full-prefix recompute, torch fp32 — the reference's ar
 FFN, and the opt-in bf16x6 FFN): rows whose tokens differ, and for each such row the gap between the two best logits of the
 ORACLE at the first differing position (a flip is a near-tie if that gap is of the size of the fp32 noise between two
 implementations, ~1e-5).  Test infrastructure (imports oracle/); not part of bench.py's default run: about 6 reactions/s on
-16 host cores.  Usage: python tools/parity_at_scale.py [--batches 24]"""
+16 host cores.  Usage: python tests/tools/parity_at_scale.py [--batches 24]"""
 import argparse
 import os
 import sys
@@ -13,7 +13,7 @@ from pathlib import Path
 
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import translation_transformer_amd as tta  # noqa: E402
 from bench import get_weights, usable_cores  # noqa: E402

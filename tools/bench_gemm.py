@@ -4,7 +4,6 @@ import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import translation_transformer_amd as tta
 from tests.util_models import tiny_state  # any model gives a session
 
