@@ -406,7 +406,7 @@ def main_beam(a):
             ach_raw = pw["gemm_flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
             ach = pw["gemm_flops"] / (net_ms * 1e-3) / 1e12
             line["roofline"] = {"kernel": "fp32 MFMA GEMM family of the verify step under the small-row policy (k_gemm3<KW> 32x32 K-split for "
-                                          "N <= 768, k_gemm2<NT> 64x64 for FFN1; v_mfma_f32_32x32x2_f32), every launch of the run",
+                                          "the K = 256 GEMMs up to N = 768, k_gemm2<NT> 64x64 for FFN1 and for FFN2 as 8 K-slices; v_mfma_f32_32x32x2_f32), every launch of the run",
                                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                                 "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
                                 "traffic_note": "no PMC pass was collected for this configuration",

@@ -316,6 +316,12 @@ struct ttx_session {
   bool gemm_v1 = false, attn_v1 = false, attn_v3 = true;
   int attn_split = -1;             // TTX_ATTN_SPLIT: -1 by launch size, 0 never, 1 always (key tiles of a head over 4 waves)
   bool tree_big_policy = false;    // TTX_TREE_BIG_POLICY=1: beam paths under the large-row-count GEMM policy too
+  bool ffn2_on_g2 = false;         // the K >= 2048 step GEMM stays on the 64x64 kernel even where k_gemm3 is allowed (set by the beam paths)
+  // The beam paths' small-row GEMM policy (TTX_TREE_*): 32x32 K-split kernel for the narrow K = 256 GEMMs, split-K 4 for the
+  // d x d projections, FFN2 as 8 K-slices on the 64x64 kernel (736 workgroups instead of 2 880 of the 32x32 one: the same
+  // latency for one batch, +8-17 % with eight batches in flight, tools/ab_beam_policy.sh)
+  int tree_gemm3_max_n = 768, tree_proj_split = 4, tree_ffn2_split = 8;
+  bool tree_ffn2_g2 = true;
   int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
   int fuse_ln_min_rows = 0;        // d-wide GEMM + LayerNorm fused (k_gemm_ln256) from this row capacity on; 0: never (slower)
   // k_gemm24 picks the tiling per launch from the live row count (all bit-identical): 128x128 tiles once there are
@@ -415,6 +421,10 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   if (const char* a3 = getenv("TTX_ATTN_V3")) s->attn_v3 = atoi(a3) != 0;
   if (const char* sp = getenv("TTX_ATTN_SPLIT")) s->attn_split = atoi(sp);
   if (const char* tb = getenv("TTX_TREE_BIG_POLICY")) s->tree_big_policy = atoi(tb) != 0;
+  if (const char* fg = getenv("TTX_TREE_FFN2_G2")) s->tree_ffn2_g2 = atoi(fg) != 0;
+  if (const char* e = getenv("TTX_TREE_GEMM3_MAX_N")) s->tree_gemm3_max_n = std::max(0, atoi(e));
+  if (const char* e = getenv("TTX_TREE_PROJ_SPLIT")) s->tree_proj_split = std::max(1, atoi(e));
+  if (const char* e = getenv("TTX_TREE_FFN2_SPLIT")) s->tree_ffn2_split = std::max(1, atoi(e));
   if (const char* fl = getenv("TTX_FUSE_LN_MIN_ROWS")) s->fuse_ln_min_rows = std::max(0, atoi(fl));
   if (const char* bt = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(bt));
   if (const char* bw = getenv("TTX_BIG_WIDE_TILES")) s->big_wide_tiles = std::max(0, atoi(bw));
@@ -464,7 +474,7 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
 static bool use_gemm3(const ttx_session* s, bool step, int N, int K, int k_per_split) {
   const int kw4 = k_per_split / 4;
   const bool ok = (k_per_split % 32 == 0) && (kw4 == 16 || kw4 == 64 || (kw4 % 128) == 0);
-  (void)K;
+  if (s->ffn2_on_g2 && K >= 2048) return false;
   return step && ok && !s->gemm_v1 && N <= s->gemm3_max_n;
 }
 
@@ -1943,11 +1953,11 @@ static int beam_enqueue_iter(const BeamJob& j, bool first, int cur) {
   k.kcache = s->tk[nxt].as<float>(); k.vcache = s->tv[nxt].as<float>(); k.src_of = s->t_src_of.as<int>(); k.want_argmax = false;
   {
     struct PolicyScope {          // few hundred step rows: the small-batch GEMM policy, as ttx_tree_step
-      ttx_session* s; int g3, ps, fs, bt;
-      explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles) {
-        if (!s->tree_big_policy) { s->gemm3_max_n = 768; s->proj_split = 4; s->ffn2_split = 8; s->big_min_tiles = 0; }
+      ttx_session* s; int g3, ps, fs, bt; bool f2;
+      explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles), f2(s_->ffn2_on_g2) {
+        if (!s->tree_big_policy) { s->gemm3_max_n = s->tree_gemm3_max_n; s->proj_split = s->tree_proj_split; s->ffn2_split = s->tree_ffn2_split; s->big_min_tiles = 0; s->ffn2_on_g2 = s->tree_ffn2_g2; }
       }
-      ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; }
+      ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; s->ffn2_on_g2 = f2; }
     } scope(s);
     TTX_TRY(run_step(s, st, k, std::min(j.p.max_len, ((j.width + 63) / 64) * 64)));
   }
@@ -2284,11 +2294,11 @@ extern "C" int ttx_beam_generate(ttx_session* s, const int64_t* d_src, int B, in
     k.kcache = s->tk[nxt].as<float>(); k.vcache = s->tv[nxt].as<float>(); k.src_of = s->t_src_of.as<int>(); k.want_argmax = false;
     {
       struct PolicyScope {
-        ttx_session* s; int g3, ps, fs, bt;
-        explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles) {
-          if (!s->tree_big_policy) { s->gemm3_max_n = 768; s->proj_split = 4; s->ffn2_split = 8; s->big_min_tiles = 0; }
+        ttx_session* s; int g3, ps, fs, bt; bool f2;
+        explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles), f2(s_->ffn2_on_g2) {
+          if (!s->tree_big_policy) { s->gemm3_max_n = s->tree_gemm3_max_n; s->proj_split = s->tree_proj_split; s->ffn2_split = s->tree_ffn2_split; s->big_min_tiles = 0; s->ffn2_on_g2 = s->tree_ffn2_g2; }
         }
-        ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; }
+        ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; s->ffn2_on_g2 = f2; }
       } scope(s);
       TTX_TRY(run_step(s, st, k, std::min(max_len, ((width + 63) / 64) * 64)));
     }
