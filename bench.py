@@ -164,35 +164,6 @@ def pmc_traffic_for(key: dict):
                   "); profiles/gemm_pmc_traffic.json lists the profiled ones")
 
 
-def ffn_bf16x6_run(tta, sd, device, make_gen, timed, warm, a, outs, raised, rows_sched, pad) -> dict:
-    os.environ["TTX_FFN_BF16X6"] = "1"          # read when a session is created
-    try:
-        m6 = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=pad, device=device)
-        g = make_gen(m6)
-        reps = max(a.inflight, -(-len(timed) // max(1, len(warm)))) if rows_sched else a.inflight
-        g.generate_many((warm * reps)[:max(a.inflight, len(timed))], in_flight=a.inflight, reorder=rows_sched)   # workspaces, graphs
-        g = make_gen(m6)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res = g.generate_many(timed, in_flight=a.inflight, reorder=rows_sched, on_error="skip")
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    finally:
-        os.environ.pop("TTX_FFN_BF16X6", None)
-    ok = [i for i, o in enumerate(res) if o is not None]
-    rows_diff = sum(int((res[i] != outs[i]).any(dim=2).any(dim=1).sum()) for i in ok if i not in raised)
-    rows_cmp = sum(int(timed[i].shape[0]) for i in ok if i not in raised)
-    out = {"value": sum(int(timed[i].shape[0]) for i in ok) / dt, "unit": "reactions/s",
-           "tokens_identical_to_fp32_run": sorted(set(range(len(timed))) - set(ok)) == sorted(raised)
-           and all(torch.equal(res[i], outs[i]) for i in ok),
-           "rows_differing_from_fp32_run": rows_diff, "rows_compared": rows_cmp,
-           "what": "both FFN GEMMs (encoder and decoder) on v_mfma_f32_32x32x16_bf16: six partial products per fp32 product, operands "
-                   "split in registers, fp32 accumulate; everything else as in the fp32 run.  Opt-in (TTX_FFN_BF16X6=1); the whole "
-                   "-m gpu suite passes under it (every golden and oracle comparison token-identical)"}
-    m6.close()
-    return out
-
-
 class _SynthTokenizer:
     """The attributes of the reference's tokenizer the Lightning module reads (tokenizer_base.py:16-40)."""
 
@@ -616,9 +587,6 @@ def main():
             line["device_model_calls"] = stats["device"]["model_calls"]
             line["device_src_tokens_padded"] = stats["device"]["src_tokens_padded"]
         if not a.timed_only:
-            # Experiment reported BESIDE the fp32 line, never instead of it: the two FFN GEMMs with every product
-            # formed from six bf16 MFMA partial products (x = hi + mid + lo exactly; fp32 accumulation; fp32-level error).
-            line["ffn_bf16x6_experiment"] = ffn_bf16x6_run(tta, sd, local_rank, make_gen, timed, warm, a, outs, raised, rows_sched, PAD)
             # The same K batches through the kept Lightning surface (src/model/lightning_model.py:209-243): a trainer
             # stand-in that only calls on_predict_start -> predict_step per batch -> on_predict_end, i.e. what main.py's
             # Trainer.predict does; predict_step serves the batches from windows decoded ahead (slot pools).

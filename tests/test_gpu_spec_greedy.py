@@ -175,11 +175,11 @@ def test_streaming_attention_fallback_matches(tta):
     gold = load_npz("gen_spec_greedy.npz")
     src, _, c, _ = fixture_tokens()
     st, cfg = tiny_state()
-    os.environ["TTX_ATTN_V1"] = "1"
+    os.environ["TTX_ATTN_FALLBACK"] = "1"
     try:
         slow = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
     finally:
-        os.environ.pop("TTX_ATTN_V1")
+        os.environ.pop("TTX_ATTN_FALLBACK")
     g = tta.TranslationInferenceGreedySpeculative(slow, 150, 10, 3, PAD, BOS, EOS, c)
     np.testing.assert_array_equal(g.generate(src.cuda()).cpu().numpy(), gold["b10_n3_d10_tokens"])
     io = load_npz("tiny_model_io.npz")

@@ -14,7 +14,12 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = PKG_DIR / "libttx_hip.so"
-SOURCES = [CSRC / "ttx_api.hip", CSRC / "ttx_kernels.hip.h", CSRC / "ttx_select.h", CSRC / "ttx_tokenizer.h", INCLUDE / "ttx.h"]
+# translation units (compiled in parallel, linked into one shared library) and the headers every one of them depends on
+UNITS = [CSRC / "ttx_api.hip", CSRC / "ttx_gemm.hip", CSRC / "ttx_attn.hip"]
+HEADERS = [CSRC / "ttx_internal.h", CSRC / "ttx_common.hip.h", CSRC / "ttx_loop_kernels.hip.h", CSRC / "ttx_select.h",
+           CSRC / "ttx_tokenizer.h", INCLUDE / "ttx.h"]
+SOURCES = UNITS + HEADERS
+OBJ_DIR = CSRC / "build"
 
 TTX_OK, TTX_ERR_INVALID, TTX_ERR_HIP, TTX_ERR_NO_DEVICE, TTX_ERR_REFERENCE, TTX_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 TTX_ERR_ROW_REPLAY = -6
@@ -139,12 +144,28 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the HIP library for gfx950 in-tree (cross-compiles without a GPU)."""
+    """Compile the HIP library for gfx950 in-tree (cross-compiles without a GPU): one object per translation unit, in
+    parallel, objects newer than their unit and every header are kept."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}",
-           "-o", str(LIB_PATH), str(CSRC / "ttx_api.hip")]
-    cmd[3:3] = os.environ.get("TTX_HIPCC_FLAGS", "").split()      # experiments: extra -D switches
+    OBJ_DIR.mkdir(exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}"] + os.environ.get("TTX_HIPCC_FLAGS", "").split()
+    newest_header = max(h.stat().st_mtime for h in HEADERS)
+    jobs, objs = [], []
+    for unit in UNITS:
+        obj = OBJ_DIR / (unit.stem + ".o")
+        objs.append(str(obj))
+        if not force and obj.exists() and obj.stat().st_mtime > max(unit.stat().st_mtime, newest_header) \
+                and not os.environ.get("TTX_HIPCC_FLAGS"):
+            continue
+        cmd = [hipcc_path(), *flags, "-c", str(unit), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,67 +1,28 @@
-// Host side of libttx_hip.so: the C ABI of include/ttx.h over the kernels of ttx_kernels.hip.h.
-// No CPU fallback exists anywhere in this file: without a gfx950 device every entry point fails.
-#include "ttx.h"
-#include "ttx_kernels.hip.h"
+// Host side of libttx_hip.so: the C ABI of include/ttx.h, the runtime around the kernels (sessions, workspaces, hipGraphs,
+// polling loops, slot pools) and the loop / bookkeeping kernels (ttx_loop_kernels.hip.h).  The GEMM and attention families
+// live in ttx_gemm.hip / ttx_attn.hip and are reached through the launchers of ttx_internal.h.
+// No CPU fallback exists anywhere in this library: without a gfx950 device every entry point fails.
+#include "ttx_internal.h"
+#include "ttx_loop_kernels.hip.h"
 #include "ttx_tokenizer.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
 #include <mutex>
-#include <set>
-#include <tuple>
-#include <string>
-#include <vector>
 
 using namespace ttx;
 
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-static int fail(int code, const std::string& msg) {
+int ttx::fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
-
-#define HIP_TRY(expr)                                                                                  \
-  do {                                                                                                 \
-    hipError_t _e = (expr);                                                                            \
-    if (_e != hipSuccess)                                                                              \
-      return fail(TTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
-                                   std::to_string(__LINE__) + ")");                                    \
-  } while (0)
-
-#define TTX_TRY(expr)        \
-  do {                       \
-    int _r = (expr);         \
-    if (_r != TTX_OK) return _r; \
-  } while (0)
-
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-
-// ------------------------------------------------------------------------------------------------
-struct LayerW {
-  // offsets (in floats) into the blob
-  size_t sa_in_w, sa_in_b, sa_out_w, sa_out_b;
-  size_t ca_in_w, ca_in_b, ca_out_w, ca_out_b;  // decoder only
-  size_t l1_w, l1_b, l2_w, l2_b;
-  size_t n1_w, n1_b, n2_w, n2_b, n3_w, n3_b;
-};
-
-struct ttx_model {
-  ttx_config cfg;
-  int device;
-  float* blob = nullptr;
-  size_t blob_floats = 0;
-  std::map<std::string, std::pair<size_t, size_t>> index;  // name -> (offset, numel)
-  std::vector<LayerW> enc, dec;
-  size_t src_emb, tgt_emb, enc_norm_w, enc_norm_b, dec_norm_w, dec_norm_b, cls_w, cls_b, pe;
-  size_t cross_kv_w, cross_kv_b;  // packed [Ld*2d, d] / [Ld*2d]: cross-attention K,V rows of every decoder layer
-  const float* p(size_t off) const { return blob + off; }
-};
 
 static void layout_add(ttx_model* m, const std::string& name, size_t numel, size_t* off_out) {
   size_t off = (m->blob_floats + 63) & ~(size_t)63;
@@ -245,116 +206,6 @@ extern "C" void ttx_model_destroy(ttx_model* m) {
   delete m;
 }
 
-// ------------------------------------------------------------------------------------------------
-struct Buf {
-  void* p = nullptr;
-  size_t cap = 0;
-  uint64_t* owner_gen = nullptr;   // the owning session's alloc_generation: bumped whenever this buffer moves
-  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-struct GraphKey {
-  int B, Ls, N, D, max_len, greedy, kcap;   // greedy: 0 speculative, 1 plain greedy, 2 speculative under the per-row rule
-  bool operator<(const GraphKey& o) const {
-    return std::tie(B, Ls, N, D, max_len, greedy, kcap) < std::tie(o.B, o.Ls, o.N, o.D, o.max_len, o.greedy, o.kcap);
-  }
-};
-
-struct ttx_session {
-  ttx_model* m;
-  std::vector<Buf*> all;
-  // activations (shared by encoder / full decoder / step)
-  Buf x, x1, x2, xf, ao, q2, hbuf, slab, qkv, logits, ckv;
-  // sources
-  Buf tok_src, src_valid, memory, memkv;
-  // full decoder
-  Buf tok_tgt, mem_pad_tmp;
-  // loop
-  Buf drafts, gen, front, act_idx, rec, pred, state, kcache, vcache, src32, outbuf, dbg_self, dbg_cross, haspad, traj, fin_step;
-  // slot pool (continuous batching)
-  Buf rstep, row_of, src_len, new_slot, pool_io, memkv_new, valid_new, drafts_new;
-  // snapshot of one verify step for the logits parity test (ttx_gen_params.want_logits)
-  Buf snap_logits, snap_act, snap_front, snap_gen, snap_state;
-  int snap_B = 0, snap_rps = 0, snap_gen_ld = 0, snap_step = 0;
-  Buf leaf_score, leaf_tok, leaf_cnt, beam_summary;
-  // native beam-speculative loop
-  Buf bs_cand_next, bs_len_next, bs_fin_next, bs_logp_next, bs_len, bs_fin, bs_active, bs_logp, bs_per_cand, bs_best_n, bs_best_slot,
-      bs_chosen, bs_parent, bs_parent_draft, bs_mark, bs_drafts_src, bs_cnt, bs_hit;
-  BeamHost* beam_host = nullptr;   // pinned + device-mapped, written by k_bs_publish
-  // tree (beam) decoding
-  Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of;
-  bool attn_debug = false;
-  bool gemm_debug = false;
-  int gemm_debug_n = 0;
-  Buf dbg_gemm;
-  HostInfo* host_info = nullptr;   // pinned + device-mapped, written by the accept kernels
-  hipStream_t own_stream = nullptr; // used by the many-batches driver
-  // Captured graphs hold raw pointers into the workspaces.  EVERY growth of a buffer of this session (whichever entry
-  // point caused it) bumps alloc_generation through Buf::owner_gen; the graph cache remembers the generation it was
-  // captured under and is dropped as soon as the two differ (graphs_current(), called before any replay or capture).
-  uint64_t alloc_generation = 0;
-  uint64_t graphs_generation = 0;
-  bool dead = false;               // a verify step never published its result (watchdog): the stream may still be stuck
-  bool use_graphs = true;
-  std::map<GraphKey, hipGraphExec_t> graphs;
-  std::set<GraphKey> warmed;
-  hipEvent_t ev_done = nullptr;
-  std::map<std::vector<int>, hipGraphExec_t> beam_graphs;   // one iteration of the beam-speculative loop per shape
-  std::set<std::vector<int>> beam_warmed;
-  void drop_graphs() {
-    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
-    graphs.clear(); warmed.clear();
-    for (auto& kv : beam_graphs) (void)hipGraphExecDestroy(kv.second);
-    beam_graphs.clear(); beam_warmed.clear();
-  }
-  void graphs_current() { if (graphs_generation != alloc_generation) { drop_graphs(); graphs_generation = alloc_generation; } }
-  DecState* host_state = nullptr;  // pinned copy target
-  bool attn_attr_set = false;
-  size_t attn_lds_limit = 0;
-  // profiling of the GEMM launches (bench.py roofline)
-  bool profile = false;
-  bool gemm_v1 = false, attn_v1 = false, attn_v3 = true;
-  int attn_split = -1;             // TTX_ATTN_SPLIT: -1 by launch size, 0 never, 1 always (key tiles of a head over 4 waves)
-  bool tree_big_policy = false;    // TTX_TREE_BIG_POLICY=1: beam paths under the large-row-count GEMM policy too
-  bool ffn2_on_g2 = false;         // the K >= 2048 step GEMM stays on the 64x64 kernel even where k_gemm3 is allowed (set by the beam paths)
-  // The beam paths' small-row GEMM policy (TTX_TREE_*): 32x32 K-split kernel for the narrow K = 256 GEMMs, split-K 4 for the
-  // d x d projections, FFN2 as 8 K-slices on the 64x64 kernel (736 workgroups instead of 2 880 of the 32x32 one: the same
-  // latency for one batch, +8-17 % with eight batches in flight, tools/ab_beam_policy.sh)
-  int tree_gemm3_max_n = 768, tree_proj_split = 4, tree_ffn2_split = 8;
-  bool tree_ffn2_g2 = true;
-  int ffn2_split = 2;              // largest split-K factor of the step's K >= 2048 GEMM (FFN2)
-  int fuse_ln_min_rows = 0;        // d-wide GEMM + LayerNorm fused (k_gemm_ln256) from this row capacity on; 0: never (slower)
-  // k_gemm24 picks the tiling per launch from the live row count (all bit-identical): 128x128 tiles once there are
-  // big_wide_tiles of them, else 128x64 tiles once there are big_min_tiles of THOSE, else 64x64.  Measured per shape in
-  // isolation (tools/bench_gemm.py, gpurun_out/gemm_bench_r2b.log): QKV at 7 936 rows 40.5 -> 35.4 us, FFN1 at 2 480 rows
-  // 39.8 -> 33.8 us under these thresholds; 0 = never a 128-row tiling.
-  int big_min_tiles = 400;
-  int big_wide_tiles = 480;
-  bool ffn_b6 = false;             // TTX_FFN_BF16X6=1 (experiment): the FFN pair's products from bf16 pieces (k_gemm24_b6)
-  int proj_split = 1;              // largest split-K factor of the step's d x d projections on the 64x64 kernel
-  int gemm3_max_n = 0;             // step GEMMs at most this wide use the 32x32 kernel (k_gemm3); 0: none
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-  size_t ev_used = 0;
-  double prof_ms = 0;
-  double prof_empty_pair_ms = -1;
-  bool host_timing = false;
-  double host_launch_us = 0;
-  long long host_captures = 0;      // TTX_HOST_TIMING: beam iteration graphs captured on this session and the host time they took
-  double host_capture_us = 0;
-  long long host_launches = 0;
-  long long prof_launches = 0;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
-  ttx_session() { for (Buf* b : {&x, &x1, &x2, &xf, &ao, &q2, &hbuf, &slab, &qkv, &logits, &ckv, &tok_src, &src_valid, &memory,
-                                 &memkv, &tok_tgt, &mem_pad_tmp, &drafts, &gen, &front, &act_idx, &rec, &pred, &state,
-                                 &kcache, &vcache, &src32, &outbuf, &dbg_self, &dbg_cross, &haspad, &traj, &fin_step, &rstep, &row_of, &src_len, &new_slot,
-                                 &pool_io, &memkv_new, &valid_new, &drafts_new, &tk[0], &tk[1], &tv[0], &tv[1],
-                                 &t_prev_len, &t_slot_of, &t_src_of, &dbg_gemm,
-                                 &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state, &leaf_score, &leaf_tok, &leaf_cnt,
-                                 &beam_summary, &bs_cand_next, &bs_len_next, &bs_fin_next, &bs_logp_next, &bs_len, &bs_fin, &bs_active,
-                                 &bs_logp, &bs_per_cand, &bs_best_n, &bs_best_slot, &bs_chosen, &bs_parent, &bs_parent_draft, &bs_mark,
-                                 &bs_drafts_src, &bs_cnt, &bs_hit}) { b->owner_gen = &alloc_generation; all.push_back(b); } }
-};
-
 // Growing a workspace must not stall the other sessions' streams: hipFree waits for the whole device, so the old
 // allocation is parked here and released at the start of a later top-level call (or when a session is destroyed),
 // when nothing of the previous call is in flight any more.  Work already enqueued keeps using the old allocation;
@@ -414,25 +265,13 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   s->use_graphs = getenv("TTX_NO_GRAPH") == nullptr;
   const char* pf = getenv("TTX_PROFILE_GEMM");
   s->profile = pf && pf[0] == '1';
-  s->gemm_v1 = getenv("TTX_GEMM_V1") != nullptr;
-  if (const char* g3 = getenv("TTX_GEMM3_MAX_N")) s->gemm3_max_n = atoi(g3);
-  if (const char* f2 = getenv("TTX_FFN2_SPLIT")) s->ffn2_split = std::max(1, atoi(f2));
-  if (const char* ps = getenv("TTX_PROJ_SPLIT")) s->proj_split = std::max(1, atoi(ps));
-  if (const char* a3 = getenv("TTX_ATTN_V3")) s->attn_v3 = atoi(a3) != 0;
-  if (const char* sp = getenv("TTX_ATTN_SPLIT")) s->attn_split = atoi(sp);
-  if (const char* tb = getenv("TTX_TREE_BIG_POLICY")) s->tree_big_policy = atoi(tb) != 0;
-  if (const char* fg = getenv("TTX_TREE_FFN2_G2")) s->tree_ffn2_g2 = atoi(fg) != 0;
-  if (const char* e = getenv("TTX_TREE_GEMM3_MAX_N")) s->tree_gemm3_max_n = std::max(0, atoi(e));
-  if (const char* e = getenv("TTX_TREE_PROJ_SPLIT")) s->tree_proj_split = std::max(1, atoi(e));
-  if (const char* e = getenv("TTX_TREE_FFN2_SPLIT")) s->tree_ffn2_split = std::max(1, atoi(e));
-  if (const char* fl = getenv("TTX_FUSE_LN_MIN_ROWS")) s->fuse_ln_min_rows = std::max(0, atoi(fl));
-  if (const char* bt = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(bt));
-  if (const char* bw = getenv("TTX_BIG_WIDE_TILES")) s->big_wide_tiles = std::max(0, atoi(bw));
-  if (const char* b6 = getenv("TTX_FFN_BF16X6")) s->ffn_b6 = atoi(b6) != 0;
-  s->attn_v1 = getenv("TTX_ATTN_V1") != nullptr;
-  s->attn_debug = getenv("TTX_ATTN_DEBUG") != nullptr;
+  // experiments: where the host switches between the bit-identical GEMM variants / tilings
+  if (const char* e = getenv("TTX_SMALL_ROWS")) s->small_rows = std::max(0, atoi(e));
+  if (const char* e = getenv("TTX_WIDE_ROWS")) s->wide_rows = std::max(0, atoi(e));
+  if (const char* e = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(e));
+  if (const char* e = getenv("TTX_ATTN_SPLIT")) s->attn_split = atoi(e);
+  if (const char* e = getenv("TTX_ATTN_FALLBACK")) s->attn_fallback = atoi(e) != 0;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
-  if (const char* gd = getenv("TTX_GEMM_DEBUG")) { s->gemm_debug = true; s->gemm_debug_n = atoi(gd); }
   *out = s;
   return TTX_OK;
 }
@@ -455,6 +294,7 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
     if (b->p) (void)hipFree(b->p);
   if (s->host_info) (void)hipHostFree(s->host_info);
   if (s->beam_host) (void)hipHostFree(s->beam_host);
+  if (s->bp_host) (void)hipHostFree(s->bp_host);
   s->drop_graphs();
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   if (s->ev_done) (void)hipEventDestroy(s->ev_done);
@@ -467,201 +307,22 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Launch helpers
-// Kernel and split-K choice depend only on (N, K) and on whether the launch belongs to a verify step (M <= a few
-// thousand rows, read from the device) or to a bulk pass (encoder, full-prefix decoder, cross K/V) — never on the
-// row count, so a sequence's arithmetic (summation order) is the same whatever batch it sits in.
-static bool use_gemm3(const ttx_session* s, bool step, int N, int K, int k_per_split) {
-  const int kw4 = k_per_split / 4;
-  const bool ok = (k_per_split % 32 == 0) && (kw4 == 16 || kw4 == 64 || (kw4 % 128) == 0);
-  if (s->ffn2_on_g2 && K >= 2048) return false;
-  return step && ok && !s->gemm_v1 && N <= s->gemm3_max_n;
+// GEMM variant of a launch (ttx_internal.h: all variants return identical bits).  Steps: by live rows; bulk passes
+// (encoder, cross K/V, full-prefix decoder) by their row count.
+static int variant_for_rows(const ttx_session* s, long long rows, bool step) {
+  if (step && rows < s->small_rows) return GV_SMALL;
+  return rows >= s->wide_rows ? GV_WIDE : GV_BIG;
 }
 
-static int choose_splits(const ttx_session* s, bool step, int N, int K) {
-  if (!step) return 1;
-  if (N <= s->gemm3_max_n && !s->gemm_v1) return (K >= 2048 && K % (256 * s->ffn2_split) == 0) ? s->ffn2_split : 1;   // k_gemm3: K also split over the 4 waves
-  int S = 1;                                                                                // k_gemm2: 64-wide tiles of a d-wide output
-  const int cap = K >= 2048 ? s->ffn2_split : s->proj_split;
-  while (S < cap && K / (S * 2) >= 64 && (K % (S * 2 * 64)) == 0 && cdiv(N, 64) * S < 32) S *= 2;
-  return S;
-}
-
-static int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* bias,
-                       float* Y, int ldy, const int* m_ptr, int Mmax, int N, int K, bool relu, int splits, long long slab_stride) {
-  if (Mmax <= 0) return TTX_OK;
-  if (K % 32) return fail(TTX_ERR_INVALID, "GEMM K must be a multiple of 32");
-  GemmArgs a;
-  a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.Y = Y; a.ldy = ldy; a.m_ptr = m_ptr;
-  a.M = Mmax; a.N = N; a.K = K; a.relu = relu ? 1 : 0;
-  a.raw = splits > 0 ? 1 : 0;
-  const int S = splits > 0 ? splits : 1;
-  a.k_per_split = K / S;
-  a.slab_stride = slab_stride;
-  a.dbg = nullptr;
-  a.big_min_tiles = 0;
-  a.big_wide_tiles = s->big_wide_tiles;
-  if (s->gemm_debug && s->dbg_gemm.p && (size_t)cdiv(N, 64) * cdiv(Mmax, 64) * S * 64 <= s->dbg_gemm.cap && N == s->gemm_debug_n && !a.raw)
-    a.dbg = s->dbg_gemm.as<unsigned long long>();
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (s->profile) {
-    if (s->ev_used == s->ev_pool.size()) {
-      hipEvent_t a0, a1;
-      HIP_TRY(hipEventCreate(&a0));
-      HIP_TRY(hipEventCreate(&a1));
-      s->ev_pool.push_back({a0, a1});
-    }
-    e0 = s->ev_pool[s->ev_used].first;
-    e1 = s->ev_pool[s->ev_used].second;
-    s->ev_used++;
-    HIP_TRY(hipEventRecord(e0, st));
-  }
-  // Kernel choice (see use_gemm3 / choose_splits): 32x32 operands-in-registers kernel for the narrow step GEMMs,
-  // 64x64 deep-prefetch kernel otherwise, the 32-deep generic kernel when K is not a multiple of 64.
-  const bool step = (m_ptr != nullptr);
-  if (use_gemm3(s, step, N, K, a.k_per_split)) {
-    dim3 grid(cdiv(N, 32), cdiv(Mmax, 32), S);
-    switch (a.k_per_split / 4) {
-      case 16: hipLaunchKernelGGL((k_gemm3<16>), grid, dim3(256), 0, st, a); break;
-      case 64: hipLaunchKernelGGL((k_gemm3<64>), grid, dim3(256), 0, st, a); break;
-      case 128: hipLaunchKernelGGL((k_gemm3<128>), grid, dim3(256), 0, st, a); break;
-      default: hipLaunchKernelGGL((k_gemm3<0>), grid, dim3(256), 0, st, a); break;
-    }
-  } else if (s->ffn_b6 && !s->gemm_v1 && a.k_per_split % 256 == 0 && (N == s->m->cfg.feedforward_dim || K == s->m->cfg.feedforward_dim)) {
-    // experiment: both FFN GEMMs (encoder and decoder, every tiling) with products from bf16 pieces
-    a.big_min_tiles = s->big_min_tiles;
-    dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
-    if (a.k_per_split == 256) hipLaunchKernelGGL((k_gemm24_b6<4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_gemm24_b6<0>), grid, dim3(256), 0, st, a);
-  } else if (a.k_per_split % 256 == 0 && !s->gemm_v1 && s->big_min_tiles > 0 &&
-             (long long)cdiv(Mmax, 128) * cdiv(N, 64) * S >= std::min(s->big_min_tiles, s->big_wide_tiles)) {
-    // enough rows (at most) for the 128x128 tiling: one launch that picks the tiling from the live row count
-    a.big_min_tiles = s->big_min_tiles;
-    dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
-    if (a.k_per_split == 256) hipLaunchKernelGGL((k_gemm24<4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_gemm24<0>), grid, dim3(256), 0, st, a);
-  } else if ((a.k_per_split == 64 || a.k_per_split == 128 || a.k_per_split % 256 == 0) && !s->gemm_v1) {
-    dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
-    switch (a.k_per_split) {
-      case 64: hipLaunchKernelGGL((k_gemm2<1>), grid, dim3(256), 0, st, a); break;
-      case 128: hipLaunchKernelGGL((k_gemm2<2>), grid, dim3(256), 0, st, a); break;
-      case 256: hipLaunchKernelGGL((k_gemm2<4>), grid, dim3(256), 0, st, a); break;
-      default: hipLaunchKernelGGL((k_gemm2<0>), grid, dim3(256), 0, st, a); break;
-    }
-  } else {
-    dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
-    hipLaunchKernelGGL((k_gemm_tn<2, 2>), grid, dim3(256), 0, st, a);
-  }
-  if (s->profile) HIP_TRY(hipEventRecord(e1, st));
-  HIP_TRY(hipGetLastError());
-  return TTX_OK;
-}
-
-static int launch_finish(ttx_session* s, hipStream_t st, const float* slabs, int n_slabs, long long slab_stride, const float* bias,
-                         const float* resid, const float* g1, const float* b1, const float* g2, const float* b2,
-                         const uint8_t* row_valid, float* Y, const int* m_ptr, int Mmax) {
-  if (Mmax <= 0) return TTX_OK;
-  const ttx_config& c = s->m->cfg;
-  FinishArgs a;
-  a.slabs = slabs; a.n_slabs = n_slabs; a.slab_stride = slab_stride; a.bias = bias; a.resid = resid;
-  a.g1 = g1; a.b1 = b1; a.g2 = g2; a.b2 = b2; a.row_valid = row_valid; a.Y = Y; a.m_ptr = m_ptr; a.M = Mmax;
-  a.d = c.embedding_dim; a.eps = c.layer_norm_eps;
-  dim3 grid(cdiv(Mmax, 4));
-  switch (c.embedding_dim / 64) {
-    case 1: hipLaunchKernelGGL((k_finish_ln<1>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_finish_ln<2>), grid, dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((k_finish_ln<4>), grid, dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL((k_finish_ln<8>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_finish_ln<16>), grid, dim3(256), 0, st, a); break;
-  }
-  HIP_TRY(hipGetLastError());
-  return TTX_OK;
-}
-
-static constexpr size_t kAttn2LdsLimit = 150 * 1024;
-
-// `groups` = sources / decoder rows / running-sequence slots; `q_per_group` = query rows of one group
-// (Ls, Lt, or N*(D+1)); for the step modes `D1`/`N` shape the draft tiles.  Uses the MFMA kernel
-// (k_attn2) whenever its LDS score/K/V images fit, else the streaming wave-per-row kernel (k_attn).
-template <int MODE>
-static int launch_attn(ttx_session* s, hipStream_t st, const AttnArgs& a, int groups, int H, int q_per_group, int max_keys,
-                       int N = 1, int D1 = 1) {
-  if (groups <= 0 || q_per_group <= 0) return TTX_OK;
-  constexpr bool step = (MODE == ATT_STEP_SELF || MODE == ATT_STEP_CROSS);
-  // step modes: q_per_group = RPS = 1 + N*D rows per running sequence.  Self-attention keys of one workgroup:
-  // prefix (< max_keys) + front row + the rows of every draft with a query among its 64 rows.
-  const int D = D1 - 1;
-  if constexpr (step) {
-    // the verify step: one wave per (sequence, head, 32 step rows), registers only — no key-count limit
-    if (s->attn_v3 && H % 4 == 0 && !s->attn_v1) {
-      // few sequences (a 32-row batch): the key tiles of one (sequence, head) are shared out over the four waves of
-      // a workgroup; many (row groups, slot pools): one wave per (sequence, head).  Bit-identical either way.
-      const int qtiles = cdiv(q_per_group, A3_QT);
-      const int keys3 = (MODE == ATT_STEP_SELF) ? max_keys + 1 + N * std::max(D, 0) : max_keys;
-      const size_t lds3 = sizeof(float) * (size_t)A3_PART * cdiv(keys3, 32);
-      const bool split = s->attn_split != 0 && (s->attn_split > 0 || (long long)groups * H * qtiles < 2048) && lds3 <= 64 * 1024;
-      if (split) hipLaunchKernelGGL((k_attn3<MODE, true>), dim3(groups, H, qtiles), dim3(256), lds3, st, a);
-      else hipLaunchKernelGGL((k_attn3<MODE, false>), dim3(groups, H / 4, qtiles), dim3(256), 0, st, a);
-      HIP_TRY(hipGetLastError());
-      return TTX_OK;
-    }
-  }
-  const int draft_keys = (D > 0) ? (std::min(N, (A2_QT + D - 2) / D + 1)) * D : 0;
-  const int keys2 = (MODE == ATT_STEP_SELF) ? max_keys + 1 + draft_keys : max_keys;
-  const size_t lds2 = attn2_lds_bytes(keys2, a2_qcap(q_per_group));
-  if (lds2 <= kAttn2LdsLimit && attn2_fits(keys2) && !s->attn_v1) {
-    const int tiles = cdiv(q_per_group, A2_QT);
-    static bool attr_set[8] = {false, false, false, false, false, false, false, false};
-    if (lds2 > 64 * 1024 && !attr_set[MODE]) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn2<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)kAttn2LdsLimit));
-      attr_set[MODE] = true;
-    }
-    hipLaunchKernelGGL((k_attn2<MODE>), dim3(groups, H, tiles), dim3(256), lds2, st, a);
-    HIP_TRY(hipGetLastError());
-    return TTX_OK;
-  }
-  const int keys1 = (MODE == ATT_STEP_SELF) ? max_keys + q_per_group : max_keys;
-  const size_t lds = attn_lds_bytes(keys1);
-  if (lds > kAttn2LdsLimit) return fail(TTX_ERR_INVALID, "sequence too long for the attention kernels' LDS score buffer");
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_attn<MODE>), dim3(groups, H, cdiv(q_per_group, ATT_MAXQ)), dim3(64), lds, st, a);
-  HIP_TRY(hipGetLastError());
-  return TTX_OK;
-}
-
+// d-wide GEMM -> slab(s) -> k_finish_ln: Y = LN2?(LN((resid + bias) + X W^T))
 static int gemm_ln(ttx_session* s, hipStream_t st, const float* X, int ldx, int K, const float* W, const float* bias,
                    const float* resid, const float* g1, const float* b1, const float* g2, const float* b2,
-                   const uint8_t* row_valid, float* Y, const int* m_ptr, int Mmax) {
+                   const uint8_t* row_valid, float* Y, const int* m_ptr, int Mmax, int variant) {
   const int d = s->m->cfg.embedding_dim;
-  const int S = choose_splits(s, m_ptr != nullptr, d, K);
-  if (m_ptr && S == 1 && d == 256 && K % 64 == 0 && s->fuse_ln_min_rows > 0 && Mmax >= s->fuse_ln_min_rows && !s->gemm_v1) {
-    // enough row capacity for 64-row workgroups to fill the chip: GEMM + finish in one launch (bit-identical result)
-    GemmLnArgs a{};
-    a.g.X = X; a.g.ldx = ldx; a.g.W = W; a.g.ldw = K; a.g.m_ptr = m_ptr; a.g.M = Mmax; a.g.N = d; a.g.K = K;
-    a.f.bias = bias; a.f.resid = resid; a.f.g1 = g1; a.f.b1 = b1; a.f.g2 = g2; a.f.b2 = b2; a.f.row_valid = row_valid; a.f.Y = Y;
-    a.f.m_ptr = m_ptr; a.f.M = Mmax; a.f.d = d; a.f.eps = s->m->cfg.layer_norm_eps;
-    hipEvent_t e1 = nullptr;
-    if (s->profile) {
-      if (s->ev_used == s->ev_pool.size()) {
-        hipEvent_t a0, a1;
-        HIP_TRY(hipEventCreate(&a0));
-        HIP_TRY(hipEventCreate(&a1));
-        s->ev_pool.push_back({a0, a1});
-      }
-      HIP_TRY(hipEventRecord(s->ev_pool[s->ev_used].first, st));
-      e1 = s->ev_pool[s->ev_used].second;
-      s->ev_used++;
-    }
-    hipLaunchKernelGGL(k_gemm_ln256, dim3(cdiv(Mmax, 64)), dim3(256), 0, st, a);
-    if (e1) HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(hipGetLastError());
-    return TTX_OK;
-  }
+  const int S = gemm_splits(d, K, m_ptr != nullptr, variant);
   const long long stride = (long long)Mmax * d;
   TTX_TRY(ensure(s->slab, sizeof(float) * (size_t)S * stride, st));
-  TTX_TRY(launch_gemm(s, st, X, ldx, W, K, nullptr, s->slab.as<float>(), d, m_ptr, Mmax, d, K, false, S, stride));
+  TTX_TRY(launch_gemm(s, st, X, ldx, W, K, nullptr, s->slab.as<float>(), d, m_ptr, Mmax, d, K, false, S, stride, variant));
   return launch_finish(s, st, s->slab.as<float>(), S, stride, bias, resid, g1, b1, g2, b2, row_valid, Y, m_ptr, Mmax);
 }
 
@@ -686,6 +347,7 @@ static int run_encoder(ttx_session* s, hipStream_t st, const int* tok, const uin
   const ttx_config& c = m->cfg;
   const int d = c.embedding_dim, F = c.feedforward_dim, H = c.num_heads;
   const int M = B * Ls;
+  const int gv = variant_for_rows(s, M, false);
   TTX_TRY(ensure_acts(s, st, (size_t)M, 1));
   float* x = s->x.as<float>();
   float* x1 = s->x1.as<float>();
@@ -699,17 +361,17 @@ static int run_encoder(ttx_session* s, hipStream_t st, const int* tok, const uin
   for (int l = 0; l < c.num_encoder_layers; ++l) {
     const LayerW& w = m->enc[l];
     const bool last = (l == c.num_encoder_layers - 1);
-    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, nullptr, M, 3 * d, d, false, 0, 0));
+    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, nullptr, M, 3 * d, d, false, 0, 0, gv));
     AttnArgs a{};
     a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d;
     a.scale = 1.0f / sqrtf((float)ATT_DH); a.L = Ls; a.tok = tok; a.pad = c.pad_token;
-    TTX_TRY(launch_attn<ATT_ENC>(s, st, a, B, H, Ls, Ls));
+    TTX_TRY(launch_attn(ATT_ENC, s, st, a, B, H, Ls, Ls));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
-                    nullptr, x1, nullptr, M));
-    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, nullptr, M, F, d, true, 0, 0));
+                    nullptr, x1, nullptr, M, gv));
+    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, nullptr, M, F, d, true, 0, 0, gv));
     TTX_TRY(gemm_ln(s, st, hb, F, F, m->p(w.l2_w), m->p(w.l2_b), x1, m->p(w.n2_w), m->p(w.n2_b),
                     last ? m->p(m->enc_norm_w) : nullptr, last ? m->p(m->enc_norm_b) : nullptr, last ? valid : nullptr,
-                    last ? memory : x, nullptr, M));
+                    last ? memory : x, nullptr, M, gv));
   }
   return TTX_OK;
 }
@@ -739,6 +401,7 @@ static int run_decoder_full(ttx_session* s, hipStream_t st, const int* tok, int 
   const ttx_config& c = m->cfg;
   const int d = c.embedding_dim, F = c.feedforward_dim, H = c.num_heads, V = c.vocab_size;
   const int M = R * Lt, Mk = Rm * Ls;
+  const int gv = variant_for_rows(s, M, false);
   TTX_TRY(ensure_acts(s, st, (size_t)M, 1));
   TTX_TRY(ensure(s->ckv, (size_t)Mk * 2 * d * 4, st));
   float* x = s->x.as<float>();
@@ -758,28 +421,28 @@ static int run_decoder_full(ttx_session* s, hipStream_t st, const int* tok, int 
   for (int l = 0; l < c.num_decoder_layers; ++l) {
     const LayerW& w = m->dec[l];
     const bool last = (l == c.num_decoder_layers - 1);
-    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, nullptr, M, 3 * d, d, false, 0, 0));
+    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, nullptr, M, 3 * d, d, false, 0, 0, gv));
     AttnArgs a{};
     a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d; a.scale = scale;
     a.L = Lt; a.tok = tok; a.pad = c.pad_token;
-    TTX_TRY(launch_attn<ATT_FULL_SELF>(s, st, a, R, H, Lt, Lt));
+    TTX_TRY(launch_attn(ATT_FULL_SELF, s, st, a, R, H, Lt, Lt));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
-                    nullptr, x1, nullptr, M));
+                    nullptr, x1, nullptr, M, gv));
     // cross attention: Q from the decoder stream, K/V re-projected from `memory` (as the reference does per call)
-    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, nullptr, M, d, d, false, 0, 0));
+    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, nullptr, M, d, d, false, 0, 0, gv));
     TTX_TRY(launch_gemm(s, st, memory, d, m->p(w.ca_in_w) + (size_t)d * d, d, m->p(w.ca_in_b) + d, ckv, 2 * d, nullptr, Mk,
-                        2 * d, d, false, 0, 0));
+                        2 * d, d, false, 0, 0, gv));
     AttnArgs ca{};
     ca.q = q2; ca.ldq = d; ca.k = ckv; ca.v = ckv + d; ca.ldkv = 2 * d; ca.out = ao; ca.d = d; ca.scale = scale;
     ca.L = Lt; ca.Lk = Ls; ca.key_pad = mem_pad; ca.mem_row = mem_row;
-    TTX_TRY(launch_attn<ATT_FULL_CROSS>(s, st, ca, R, H, Lt, Ls));
+    TTX_TRY(launch_attn(ATT_FULL_CROSS, s, st, ca, R, H, Lt, Ls));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
-                    nullptr, x2, nullptr, M));
-    TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, nullptr, M, F, d, true, 0, 0));
+                    nullptr, x2, nullptr, M, gv));
+    TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, nullptr, M, F, d, true, 0, 0, gv));
     TTX_TRY(gemm_ln(s, st, hb, F, F, m->p(w.l2_w), m->p(w.l2_b), x2, m->p(w.n3_w), m->p(w.n3_b),
-                    last ? m->p(m->dec_norm_w) : nullptr, last ? m->p(m->dec_norm_b) : nullptr, nullptr, last ? xf : x, nullptr, M));
+                    last ? m->p(m->dec_norm_w) : nullptr, last ? m->p(m->dec_norm_b) : nullptr, nullptr, last ? xf : x, nullptr, M, gv));
   }
-  return launch_gemm(s, st, xf, d, m->p(m->cls_w), d, m->p(m->cls_b), logits, V, nullptr, M, V, d, false, 0, 0);
+  return launch_gemm(s, st, xf, d, m->p(m->cls_w), d, m->p(m->cls_b), logits, V, nullptr, M, V, d, false, 0, 0, gv);
 }
 
 extern "C" int ttx_decode_tgt(ttx_session* s, const int64_t* d_tgt, int R, int Lt, const float* d_memory,
@@ -861,6 +524,7 @@ struct StepCtx {
   const int* src_of = nullptr;     // running row -> source row (tree decoding)
   const int* src_len = nullptr;    // slot pool: source keys per slot
   bool want_argmax = true;
+  int variant = GV_BIG;            // GemmVariant of this step's launches (bit-identical results; chosen from the live row count)
 };
 
 static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) {
@@ -896,32 +560,30 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     const LayerW& w = m->dec[l];
     const bool last = (l == Ld - 1);
     float* qkv = s->qkv.as<float>() + (size_t)l * qkv_layer;
-    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, m_ptr, Mmax, 3 * d, d, false, 0, 0));
+    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, m_ptr, Mmax, 3 * d, d, false, 0, 0, k.variant));
     AttnArgs a{};
     a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d; a.scale = scale;
     a.tok = s->gen.as<int>(); a.pad = c.pad_token; a.st = dst; a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>();
     a.kcache = (k.kcache ? k.kcache : s->kcache.as<float>()) + (size_t)l * cache_layer;
     a.vcache = (k.vcache ? k.vcache : s->vcache.as<float>()) + (size_t)l * cache_layer;
     a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D = k.D;
-    if (s->attn_debug && l == Ld - 1) a.dbg = s->dbg_self.as<unsigned long long>();
-    TTX_TRY(launch_attn<ATT_STEP_SELF>(s, st, a, k.B, H, RPS, kcap, k.N, D1));
+    TTX_TRY(launch_attn(ATT_STEP_SELF, s, st, a, k.B, H, RPS, kcap, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
-                    nullptr, x1, m_ptr, Mmax));
-    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, m_ptr, Mmax, d, d, false, 0, 0));
+                    nullptr, x1, m_ptr, Mmax, k.variant));
+    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, m_ptr, Mmax, d, d, false, 0, 0, k.variant));
     AttnArgs ca{};
     ca.q = q2; ca.ldq = d; ca.k = s->memkv.as<float>() + (size_t)l * 2 * d; ca.v = ca.k + d; ca.ldkv = Ld * 2 * d;
     ca.out = ao; ca.d = d; ca.scale = scale; ca.Lk = k.Ls; ca.key_pad = s->src_valid.as<uint8_t>();
     ca.st = dst; ca.act_idx = s->act_idx.as<int>(); ca.front = s->front.as<int>(); ca.N = k.N; ca.D = k.D;
     ca.src_of = k.src_of; ca.src_len = k.src_len;
-    if (s->attn_debug && l == Ld - 1) ca.dbg = s->dbg_cross.as<unsigned long long>();
-    TTX_TRY(launch_attn<ATT_STEP_CROSS>(s, st, ca, k.B, H, RPS, k.Ls, k.N, D1));
+    TTX_TRY(launch_attn(ATT_STEP_CROSS, s, st, ca, k.B, H, RPS, k.Ls, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
-                    nullptr, x2, m_ptr, Mmax));
-    TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, m_ptr, Mmax, F, d, true, 0, 0));
+                    nullptr, x2, m_ptr, Mmax, k.variant));
+    TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, m_ptr, Mmax, F, d, true, 0, 0, k.variant));
     TTX_TRY(gemm_ln(s, st, hb, F, F, m->p(w.l2_w), m->p(w.l2_b), x2, m->p(w.n3_w), m->p(w.n3_b),
-                    last ? m->p(m->dec_norm_w) : nullptr, last ? m->p(m->dec_norm_b) : nullptr, nullptr, last ? xf : x, m_ptr, Mmax));
+                    last ? m->p(m->dec_norm_w) : nullptr, last ? m->p(m->dec_norm_b) : nullptr, nullptr, last ? xf : x, m_ptr, Mmax, k.variant));
   }
-  TTX_TRY(launch_gemm(s, st, xf, d, m->p(m->cls_w), d, m->p(m->cls_b), logits, V, m_ptr, Mmax, V, d, false, 0, 0));
+  TTX_TRY(launch_gemm(s, st, xf, d, m->p(m->cls_w), d, m->p(m->cls_b), logits, V, m_ptr, Mmax, V, d, false, 0, 0, k.variant));
   if (k.want_argmax) {
     hipLaunchKernelGGL(k_argmax, dim3(cdiv(Mmax, 4)), dim3(256), 0, st, logits, V, s->pred.as<int>(), m_ptr, Mmax);
     HIP_TRY(hipGetLastError());
@@ -1043,16 +705,6 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   TTX_TRY(ensure(s->state, sizeof(DecState), st));
   TTX_TRY(ensure(s->logits, Mmax * V * 4, st));
   TTX_TRY(ensure(s->outbuf, (size_t)B * max_len * 8, st));
-  if (s->gemm_debug) {
-    TTX_TRY(ensure(s->dbg_gemm, (size_t)64 * 4096, st));
-    HIP_TRY(hipMemsetAsync(s->dbg_gemm.p, 0, (size_t)64 * 4096, st));
-  }
-  if (s->attn_debug) {
-    TTX_TRY(ensure(s->dbg_self, (size_t)B * c.num_heads * 8 * 8, st));
-    TTX_TRY(ensure(s->dbg_cross, (size_t)B * c.num_heads * 8 * 8, st));
-    HIP_TRY(hipMemsetAsync(s->dbg_self.p, 0, (size_t)B * c.num_heads * 64, st));
-    HIP_TRY(hipMemsetAsync(s->dbg_cross.p, 0, (size_t)B * c.num_heads * 64, st));
-  }
   TTX_TRY(ensure(s->kcache, (size_t)Ld * B * g.k.Lc * d * 4, st));
   TTX_TRY(ensure(s->vcache, (size_t)Ld * B * g.k.Lc * d * 4, st));
   // the encoder and the step share the activation buffers; size them for the larger of the two
@@ -1067,8 +719,9 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   // encoder once per batch (:60-61) + cross-attention K/V of every decoder layer once per source
   TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
   TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));
+  const int gv = variant_for_rows(s, (long long)B * Ls, false);
   TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv.as<float>(),
-                      Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0));
+                      Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0, gv));
   // drafts from src[:, 1:] (:64-73): min_draft_len 1, max_draft_len max_len
   if (!greedy)
     TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls, 1, B, Ls - 1, N, D, p->eos_token, p->pad_token,
@@ -1093,6 +746,7 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
   s->host_info->stop = 0;
   s->host_info->steps_done = 0;
   s->host_info->width = 1;
+  s->host_info->n_active = B;
   hipLaunchKernelGGL(k_loop_init, dim3(64), dim3(256), 0, st, g.la);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_b, st));
@@ -1104,7 +758,11 @@ static int gen_start(GenJob& j, ttx_session* s, hipStream_t st, const int64_t* d
 // first use.  `width_bound` bounds the reference's generated width when the step runs.
 static int gen_launch_step(GenJob& j, int width_bound) {
   ttx_session* s = j.s;
-  const StepCtx& k = j.g.k;
+  StepCtx k = j.g.k;
+  // GEMM variant from the rows this step will have (published by the previous step's accept kernel; plain greedy decoding
+  // keeps all B rows): a free choice, every variant returns the same bits
+  const int live = j.greedy ? k.B : std::max(1, (int)((volatile HostInfo*)s->host_info)->n_active);
+  k.variant = variant_for_rows(s, (long long)live * step_rps(k.N, k.D), true);
   // prefix keys this step can see: < width_bound; bucket the LDS images of the self-attention in steps of 64 keys
   int kcap = std::min(k.max_len, ((std::max(width_bound, 1) + 63) / 64) * 64);
   const bool snapshot = (k.p.want_logits > 0 && k.p.want_logits == j.launched + 1);
@@ -1131,7 +789,7 @@ static int gen_launch_step(GenJob& j, int width_bound) {
     ++j.launched;
     return TTX_OK;
   }
-  GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, j.greedy ? 1 : (j.g.la.row_rule ? 2 : 0), kcap};
+  GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, j.greedy ? 1 : (j.g.la.row_rule ? 2 : 0), kcap, k.variant};
   s->graphs_current();
   auto it = s->graphs.find(key);
   if (it == s->graphs.end()) {
@@ -1234,48 +892,6 @@ static int gen_finish_collect(GenJob& j) {
     j.stats->decode_ms = ms;
   }
   collect_gemm_profile(s, j.st);
-  if (s->gemm_debug && s->dbg_gemm.p) {
-    // diagnostic: phases of the workgroups of the last GEMM launch with N == TTX_GEMM_DEBUG
-    // (stamps: 0 start, 1 row count known, 2 first K tile staged, 3 MFMA loop done, 4 stores drained)
-    std::vector<unsigned long long> h(8 * 4096);
-    if (hipMemcpy(h.data(), s->dbg_gemm.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-      double acc[4] = {0, 0, 0, 0};
-      unsigned long long first = ~0ull, last = 0;
-      int n = 0;
-      for (int i = 0; i < 4096; ++i) {
-        const unsigned long long* q = &h[(size_t)i * 8];
-        if (!q[0] || !q[4]) continue;
-        for (int ph = 0; ph < 4; ++ph) acc[ph] += (double)(q[ph + 1] - q[ph]) * 0.01;
-        first = std::min(first, q[0]);
-        last = std::max(last, q[4]);
-        ++n;
-      }
-      if (n)
-        fprintf(stderr, "[ttx gemm debug] N=%d workgroups=%d  m_ptr=%.2f stage=%.2f mfma=%.2f store=%.2f us; first start -> last end %.2f us\n",
-                s->gemm_debug_n, n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, (double)(last - first) * 0.01);
-    }
-  }
-  if (s->attn_debug) {
-    // diagnostic: phase durations (us) of the LAST step's last-layer attention launches, averaged over the
-    // workgroups that ran (stamps: 0 start, 1 staged, 2 QK, 3 softmax, 4 PV, 5 stored (tile 0), 6 end)
-    const int nb = j.g.k.B * s->m->cfg.num_heads;
-    std::vector<unsigned long long> h((size_t)nb * 8);
-    for (int which = 0; which < 2; ++which) {
-      Buf& b = which ? s->dbg_cross : s->dbg_self;
-      if (hipMemcpy(h.data(), b.p, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
-      double acc[6] = {0, 0, 0, 0, 0, 0};
-      int n = 0;
-      for (int i = 0; i < nb; ++i) {
-        const unsigned long long* q = &h[(size_t)i * 8];
-        if (!q[0] || !q[6]) continue;
-        for (int ph = 0; ph < 6; ++ph) acc[ph] += (double)(q[ph + 1] - q[ph]) * 0.01;
-        ++n;
-      }
-      if (n)
-        fprintf(stderr, "[ttx attn debug] %s blocks=%d stage=%.2f qk=%.2f softmax=%.2f pv=%.2f store=%.2f tile1=%.2f us\n",
-                which ? "cross" : "self", n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n);
-    }
-  }
   j.phase = 0;
   if (j.stats) j.stats->status = hs.error == 3 ? TTX_ERR_ROW_REPLAY : (hs.error ? TTX_ERR_REFERENCE : TTX_OK);
   if (hs.error == 3)
@@ -1437,8 +1053,9 @@ static int pool_admit(PoolJob& j, const int64_t* d_src_rows, int ld_src, int R, 
                      s->valid_new.as<uint8_t>(), R, Ls_new, c.pad_token);
   HIP_TRY(hipGetLastError());
   TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->valid_new.as<uint8_t>(), R, Ls_new, s->memory.as<float>()));
+  const int gv = variant_for_rows(s, (long long)R * Ls_new, false);
   TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv_new.as<float>(),
-                      kv_row, nullptr, R * Ls_new, kv_row, d, false, 0, 0));
+                      kv_row, nullptr, R * Ls_new, kv_row, d, false, 0, 0, gv));
   TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls_new, 1, R, Ls_new - 1, k.N, k.D, k.p.eos_token, k.p.pad_token,
                                   k.p.replace_token, s->drafts_new.as<int>()));
   PoolAdmitArgs a{};
@@ -1461,12 +1078,13 @@ static int pool_admit(PoolJob& j, const int64_t* d_src_rows, int ld_src, int R, 
   return TTX_OK;
 }
 
-static int pool_launch_step(PoolJob& j) {
+static int pool_launch_step(PoolJob& j, int n_live) {
   ttx_session* s = j.s;
-  const StepCtx& k = j.g.k;
+  StepCtx k = j.g.k;
+  k.variant = variant_for_rows(s, (long long)n_live * step_rps(k.N, k.D), true);     // free choice: identical bits
   const int kcap = k.max_len;
   const bool use_graph = s->use_graphs && !s->profile;
-  GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, 3, kcap};
+  GraphKey key{k.B, k.Ls, k.N, k.D, k.max_len, 3, kcap, k.variant};
   s->graphs_current();
   auto it = s->graphs.find(key);
   if (!use_graph || (it == s->graphs.end() && !s->warmed.count(key))) {
@@ -1586,7 +1204,7 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
           j.phase = 2;
         } else {
           if (j.launched > (long long)(p->max_len + 2) * (R_total + 1)) { rc_final = fail(TTX_ERR_HIP, "decode loop failed to terminate"); break; }
-          rc_final = pool_launch_step(j);
+          rc_final = pool_launch_step(j, n_act);
         }
         progressed = true;
       } else if (j.phase == 2) {
@@ -1765,10 +1383,9 @@ extern "C" int ttx_ragged_topk(ttx_session* s, const float* d_score, const int32
   if (G == 0) return TTX_OK;
   HIP_TRY(hipSetDevice(s->m->device));
   const size_t lds = (size_t)max_group * 4;
-  static bool attr = false;
-  if (lds > 64 * 1024 && !attr) {
+  if (lds > 64 * 1024 && !s->attr_topk) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ragged_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr = true;
+    s->attr_topk = true;
   }
   RaggedTopkArgs a{d_score, d_offsets, k, d_top, d_idx};
   hipLaunchKernelGGL(k_ragged_topk, dim3(G), dim3(256), lds, (hipStream_t)stream, a);
@@ -1791,6 +1408,8 @@ struct BeamJob {
   // loop scalars
   int n_cand = 0, beam = 1, dl = 0, width = 1, empty_cols = 0, after_last = 1, room = 0, prev_dl = 0, cur = 0;
   int launched = 0;
+  int n_eos = 0;             // candidates holding EOS after the previous iteration (they are not decoded)
+  int variant = GV_BIG;      // GemmVariant of the iteration about to be enqueued (from the live candidates; identical bits)
   int phase = 0;             // 0 idle, 1 iteration in flight, 2 finishing, 3 done
   bool any_iteration = false;
   ttx_beam_stats acc{};
@@ -1876,8 +1495,9 @@ static int beam_start(BeamJob& j, ttx_session* s, hipStream_t st, const int64_t*
   // encoder + cross K/V once per source (:439 / :626); drafts (:430) or the draft library (:603-615)
   TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
   TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));
+  const int gv = variant_for_rows(s, (long long)B * Ls, false);
   TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv.as<float>(),
-                      Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0));
+                      Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0, gv));
   if (j.smart)
     TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls, 0, B, Ls, j.n_lib, j.lib_ld, p->eos_token, p->pad_token,
                                     p->replace_token, s->bs_drafts_src.as<int>()));
@@ -1951,16 +1571,8 @@ static int beam_enqueue_iter(const BeamJob& j, bool first, int cur) {
   StepCtx k{};
   k.B = MC; k.Ls = j.Ls; k.N = j.N; k.D = dl; k.Lc = j.Lc; k.gen_ld = j.gen_ld; k.max_len = j.p.max_len;
   k.kcache = s->tk[nxt].as<float>(); k.vcache = s->tv[nxt].as<float>(); k.src_of = s->t_src_of.as<int>(); k.want_argmax = false;
-  {
-    struct PolicyScope {          // few hundred step rows: the small-batch GEMM policy, as ttx_tree_step
-      ttx_session* s; int g3, ps, fs, bt; bool f2;
-      explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles), f2(s_->ffn2_on_g2) {
-        if (!s->tree_big_policy) { s->gemm3_max_n = s->tree_gemm3_max_n; s->proj_split = s->tree_proj_split; s->ffn2_split = s->tree_ffn2_split; s->big_min_tiles = 0; s->ffn2_on_g2 = s->tree_ffn2_g2; }
-      }
-      ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; s->ffn2_on_g2 = f2; }
-    } scope(s);
-    TTX_TRY(run_step(s, st, k, std::min(j.p.max_len, ((j.width + 63) / 64) * 64)));
-  }
+  k.variant = j.variant;
+  TTX_TRY(run_step(s, st, k, std::min(j.p.max_len, ((j.width + 63) / 64) * 64)));
   BeamHitsArgs ha{};
   ha.logits = s->logits.as<float>(); ha.V = V; ha.finished = s->bs_fin.as<uint8_t>(); ha.slot_of = s->t_slot_of.as<int>();
   ha.per_cand = s->bs_per_cand.as<int>(); ha.drafts32 = s->drafts.as<int>();
@@ -1992,10 +1604,9 @@ static int beam_enqueue_iter(const BeamJob& j, bool first, int cur) {
                          s->bs_parent.as<int>(), s->bs_parent_draft.as<int>(), s->bs_mark.as<int>(), s->beam_summary.as<int>(),
                          s->bs_len_next.as<int>(), s->bs_fin_next.as<uint8_t>()};
   const size_t lds = 2 * (size_t)j.beam * (dl + 1) * j.K * 4;
-  static bool attr = false;
-  if (lds > 64 * 1024 && !attr) {
+  if (lds > 64 * 1024 && !s->attr_select) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_beam_select<int>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr = true;
+    s->attr_select = true;
   }
   hipLaunchKernelGGL(k_beam_select<int>, dim3(j.B), dim3(256), lds, st, sa);
   HIP_TRY(hipGetLastError());
@@ -2016,13 +1627,14 @@ static int beam_launch_iter(BeamJob& j) {
   const bool first = j.launched == 0;
   const int cur = j.cur;
   const int kcap = std::min(j.p.max_len, ((j.width + 63) / 64) * 64);
+  j.variant = variant_for_rows(s, (long long)std::max(1, j.n_cand - j.n_eos) * step_rps(j.N, j.dl), true);
   int rc = TTX_OK;
   if (!s->use_graphs || s->profile) {
     rc = beam_enqueue_iter(j, first, cur);
   } else {
     s->graphs_current();
     const std::vector<int> key{j.B, j.Ls, j.K, j.N, j.D0, j.smart ? 1 : 0, j.p.max_len, j.n_cand, j.beam, j.dl, j.prev_dl, cur, kcap,
-                               first ? 1 : 0, j.p.pad_token, j.p.bos_token, j.p.eos_token};
+                               first ? 1 : 0, j.p.pad_token, j.p.bos_token, j.p.eos_token, j.variant};
     auto it = s->beam_graphs.find(key);
     if (it == s->beam_graphs.end() && !s->beam_warmed.count(key)) {
       s->beam_warmed.insert(key);
@@ -2071,6 +1683,7 @@ static bool beam_after_iter(BeamJob& j) {
   j.acc.produced_non_pad_tokens += acc_sum + acc_cnt;
   j.n_cand = j.B * j.K;
   j.beam = j.K;
+  j.n_eos = n_eos;
   if (n_eos == j.B * j.K) return false;                             // :586
   const int max_real = j.gen_ld - min_pad;                          // longest new row
   j.empty_cols = j.width - max_real;                                // min over rows of their PAD count (:592)
@@ -2248,15 +1861,16 @@ extern "C" int ttx_beam_generate(ttx_session* s, const int64_t* d_src, int B, in
   // beam (:120-124): identical rows, so the beams of a source share its memory row here
   TTX_TRY(prepare_tokens(st, d_src, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B * Ls, c.pad_token));
   TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->src_valid.as<uint8_t>(), B, Ls, s->memory.as<float>()));
+  const int gv = variant_for_rows(s, (long long)B * Ls, false);
   TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv.as<float>(),
-                      Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0));
+                      Ld * 2 * d, nullptr, B * Ls, Ld * 2 * d, d, false, 0, 0, gv));
   hipLaunchKernelGGL(k_bs_init, dim3(64), dim3(256), 0, st, s->bs_cand_next.as<int64_t>(), ld, s->bs_len_next.as<int>(),
                      s->bs_fin_next.as<uint8_t>(), s->bs_logp_next.as<float>(), s->bs_parent.as<int>(), s->bs_parent_draft.as<int>(),
                      MC, B, p->bos_token, p->pad_token, s->bs_cnt.as<BeamCounters>());
   HIP_TRY(hipGetLastError());
 
   const long long cache_seq = (long long)Lc * d, cache_layer = (long long)MC * cache_seq;
-  int n_cand = B, beam = 1, width = 1, cur = 0, launched = 0;
+  int n_cand = B, beam = 1, width = 1, cur = 0, launched = 0, n_eos = 0;
   const int max_iters = max_len - 1;                 // the <BOS> step plus `predictions - 1` loop iterations (:127-131)
   auto enqueue = [&](bool first) -> int {
     BeamPrepArgs pa{};
@@ -2292,16 +1906,8 @@ extern "C" int ttx_beam_generate(ttx_session* s, const int64_t* d_src, int B, in
     StepCtx k{};
     k.B = MC; k.Ls = Ls; k.N = 1; k.D = 0; k.Lc = Lc; k.gen_ld = ld; k.max_len = max_len;
     k.kcache = s->tk[nxt].as<float>(); k.vcache = s->tv[nxt].as<float>(); k.src_of = s->t_src_of.as<int>(); k.want_argmax = false;
-    {
-      struct PolicyScope {
-        ttx_session* s; int g3, ps, fs, bt; bool f2;
-        explicit PolicyScope(ttx_session* s_) : s(s_), g3(s_->gemm3_max_n), ps(s_->proj_split), fs(s_->ffn2_split), bt(s_->big_min_tiles), f2(s_->ffn2_on_g2) {
-          if (!s->tree_big_policy) { s->gemm3_max_n = s->tree_gemm3_max_n; s->proj_split = s->tree_proj_split; s->ffn2_split = s->tree_ffn2_split; s->big_min_tiles = 0; s->ffn2_on_g2 = s->tree_ffn2_g2; }
-        }
-        ~PolicyScope() { s->gemm3_max_n = g3; s->proj_split = ps; s->ffn2_split = fs; s->big_min_tiles = bt; s->ffn2_on_g2 = f2; }
-      } scope(s);
-      TTX_TRY(run_step(s, st, k, std::min(max_len, ((width + 63) / 64) * 64)));
-    }
+    k.variant = variant_for_rows(s, (long long)std::max(1, n_cand - n_eos), true);
+    TTX_TRY(run_step(s, st, k, std::min(max_len, ((width + 63) / 64) * 64)));
     BeamStepArgs sa{};
     sa.logits = s->logits.as<float>(); sa.V = V; sa.slot_of = s->t_slot_of.as<int>(); sa.finished = s->bs_fin.as<uint8_t>();
     sa.score = s->bs_logp.as<float>(); sa.gen = s->gen.as<int>(); sa.ld = ld; sa.width = width;
@@ -2310,10 +1916,9 @@ extern "C" int ttx_beam_generate(ttx_session* s, const int64_t* d_src, int B, in
     sa.new_len = s->bs_len_next.as<int>(); sa.new_finished = s->bs_fin_next.as<uint8_t>(); sa.parent_draft = s->bs_parent_draft.as<int>();
     sa.summary = s->beam_summary.as<int>();
     const size_t lds = (size_t)beam * V * 4;
-    static bool attr = false;
-    if (lds > 64 * 1024 && !attr) {
+    if (lds > 64 * 1024 && !s->attr_step) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_beam_step), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr = true;
+      s->attr_step = true;
     }
     hipLaunchKernelGGL(k_beam_step, dim3(B), dim3(256), lds, st, sa);
     HIP_TRY(hipGetLastError());
@@ -2337,7 +1942,8 @@ extern "C" int ttx_beam_generate(ttx_session* s, const int64_t* d_src, int B, in
     }
     width += 1;
     n_cand = B * K; beam = K;
-    if (bh->summary[0] == B * K && !first) break;                   // :166 (the check sits inside the loop, after the first step)
+    n_eos = bh->summary[0];
+    if (n_eos == B * K && !first) break;                   // :166 (the check sits inside the loop, after the first step)
   }
   HIP_TRY(hipMemcpy2DAsync(d_out, (size_t)max_len * 8, s->bs_cand_next.p, (size_t)ld * 8, (size_t)width * 8, (size_t)B * K,
                            hipMemcpyDeviceToDevice, st));
@@ -2444,128 +2050,10 @@ extern "C" int ttx_tokenizer_decode(const ttx_tokenizer* t, const int64_t* ids, 
   return (int)len;
 }
 
-// Development aid (tools/bench_gemm.py): one GEMM shape in isolation.  variant 2 = k_gemm2, 3 = k_gemm3, 4 = k_gemm4;
-// `splits` as in launch_gemm (0: bias/relu epilogue, >0: raw slabs).  Reports microseconds per launch over `reps`
-// back-to-back launches and the largest absolute difference of the (slab-summed) result to k_gemm2's.
+// Development aid (tools/bench_gemm.py): one GEMM shape in isolation (ttx_gemm.hip: gemm_bench).
 extern "C" int ttx_debug_gemm_bench(ttx_session* s, int M, int N, int K, int splits, int variant, int reps, double* us_per_launch,
                                     double* max_abs_diff) {
-  if (!s || M <= 0 || N <= 0 || K <= 0 || K % 64 || reps <= 0) return fail(TTX_ERR_INVALID, "bad argument to ttx_debug_gemm_bench");
-  HIP_TRY(hipSetDevice(s->m->device));
-  const int S = splits > 0 ? splits : 1;
-  if (K % S || (K / S) % 64) return fail(TTX_ERR_INVALID, "K / splits must be a multiple of 64");
-  std::vector<float> hx((size_t)M * K), hw((size_t)N * K), hb(N);
-  uint64_t z = 0x9E3779B97F4A7C15ull;
-  auto rnd = [&]() { z ^= z << 13; z ^= z >> 7; z ^= z << 17; return (float)((z >> 40) & 0xffff) / 65536.f - 0.5f; };
-  for (auto& v : hx) v = rnd();
-  for (auto& v : hw) v = rnd() * 0.125f;
-  for (auto& v : hb) v = rnd();
-  float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dref = nullptr;
-  int* dm = nullptr;
-  HIP_TRY(hipMalloc(&dx, hx.size() * 4));
-  HIP_TRY(hipMalloc(&dw, hw.size() * 4));
-  HIP_TRY(hipMalloc(&db, hb.size() * 4));
-  HIP_TRY(hipMalloc(&dy, (size_t)S * M * N * 4));
-  HIP_TRY(hipMalloc(&dref, (size_t)S * M * N * 4));
-  HIP_TRY(hipMalloc(&dm, 4));
-  HIP_TRY(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dm, &M, 4, hipMemcpyHostToDevice));
-  GemmArgs a;
-  a.X = dx; a.ldx = K; a.W = dw; a.ldw = K; a.bias = db; a.Y = dy; a.ldy = N; a.m_ptr = dm; a.M = M; a.N = N; a.K = K;
-  a.relu = 0; a.raw = splits > 0 ? 1 : 0; a.k_per_split = K / S; a.slab_stride = (long long)M * N; a.dbg = nullptr;
-  a.big_min_tiles = s->big_min_tiles;
-  a.big_wide_tiles = s->big_wide_tiles;
-  if ((variant == 24 || variant == 66) && (K / S) % 256) return fail(TTX_ERR_INVALID, "variants 24 / 66 need K / splits to be a multiple of 256");
-  hipStream_t st = nullptr;
-  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  auto launch = [&](int var, const GemmArgs& g) {
-    if (var == 24) {
-      dim3 grid(cdiv(N, 64), cdiv(M, 64), S);
-      if (g.k_per_split == 256) hipLaunchKernelGGL((k_gemm24<4>), grid, dim3(256), 0, st, g);
-      else hipLaunchKernelGGL((k_gemm24<0>), grid, dim3(256), 0, st, g);
-    } else if (var == 4) {
-      hipLaunchKernelGGL(k_gemm4, dim3(cdiv(N, 128), cdiv(M, 128), S), dim3(256), 0, st, g);
-    } else if (var == 66) {
-      dim3 grid(cdiv(N, 64), cdiv(M, 64), S);
-      if (g.k_per_split == 256) hipLaunchKernelGGL((k_gemm24_b6<4>), grid, dim3(256), 0, st, g);
-      else hipLaunchKernelGGL((k_gemm24_b6<0>), grid, dim3(256), 0, st, g);
-    } else if (var == 46) {
-      hipLaunchKernelGGL(k_gemm46, dim3(cdiv(N, 64), cdiv(M, 128), S), dim3(256), 0, st, g);
-    } else if (var == 3) {
-      dim3 grid(cdiv(N, 32), cdiv(M, 32), S);
-      switch (g.k_per_split / 4) {
-        case 16: hipLaunchKernelGGL((k_gemm3<16>), grid, dim3(256), 0, st, g); break;
-        case 64: hipLaunchKernelGGL((k_gemm3<64>), grid, dim3(256), 0, st, g); break;
-        case 128: hipLaunchKernelGGL((k_gemm3<128>), grid, dim3(256), 0, st, g); break;
-        default: hipLaunchKernelGGL((k_gemm3<0>), grid, dim3(256), 0, st, g); break;
-      }
-    } else {
-      dim3 grid(cdiv(N, 64), cdiv(M, 64), S);
-      switch (g.k_per_split) {
-        case 64: hipLaunchKernelGGL((k_gemm2<1>), grid, dim3(256), 0, st, g); break;
-        case 128: hipLaunchKernelGGL((k_gemm2<2>), grid, dim3(256), 0, st, g); break;
-        case 256: hipLaunchKernelGGL((k_gemm2<4>), grid, dim3(256), 0, st, g); break;
-        default: hipLaunchKernelGGL((k_gemm2<0>), grid, dim3(256), 0, st, g); break;
-      }
-    }
-  };
-  GemmArgs ref = a;
-  ref.Y = dref;
-  launch(2, ref);
-  unsigned long long* ddbg = nullptr;
-  const size_t n_wg4 = (size_t)cdiv(N, 128) * cdiv(M, 128) * S;
-  if (variant == 14) {       // k_gemm4 with per-workgroup phase stamps of its second tile pair
-    HIP_TRY(hipMalloc(&ddbg, n_wg4 * 64));
-    HIP_TRY(hipMemset(ddbg, 0, n_wg4 * 64));
-    a.dbg = ddbg;
-    variant = 4;
-  }
-  for (int i = 0; i < 3; ++i) launch(variant, a);
-  HIP_TRY(hipGetLastError());
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) launch(variant, a);
-  HIP_TRY(hipEventRecord(e1, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  if (us_per_launch) *us_per_launch = 1e3 * ms / reps;
-  if (max_abs_diff) {
-    std::vector<float> y((size_t)S * M * N), yr((size_t)S * M * N);
-    HIP_TRY(hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(yr.data(), dref, yr.size() * 4, hipMemcpyDeviceToHost));
-    double worst = 0;
-    for (size_t i = 0; i < (size_t)M * N; ++i) {
-      double u = 0, v = 0;
-      for (int k = 0; k < S; ++k) { u += y[(size_t)k * M * N + i]; v += yr[(size_t)k * M * N + i]; }
-      worst = std::max(worst, std::fabs(u - v));
-    }
-    *max_abs_diff = worst;
-  }
-  if (ddbg) {
-    std::vector<unsigned long long> h(n_wg4 * 8);
-    HIP_TRY(hipMemcpy(h.data(), ddbg, h.size() * 8, hipMemcpyDeviceToHost));
-    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-    size_t n = 0;
-    for (size_t w = 0; w < n_wg4; ++w) {
-      const unsigned long long* q = &h[w * 8];
-      if (!q[0] || !q[7]) continue;
-      for (int k = 0; k < 7; ++k) acc[k] += (double)(q[k + 1] - q[k]);
-      ++n;
-    }
-    if (n)
-      fprintf(stderr, "[ttx gemm4 stamps] %zu workgroups, shader cycles: lds-write(f0) %.0f | issue loads %.0f | barrier %.0f | mma(0) %.0f | "
-                      "write+loads(f1) %.0f | barrier %.0f | mma(1) %.0f\n", n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n,
-              acc[5] / n, acc[6] / n);
-    (void)hipFree(ddbg);
-  }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipStreamDestroy(st);
-  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dref); (void)hipFree(dm);
-  return TTX_OK;
+  return gemm_bench(s, M, N, K, splits, variant, reps, us_per_launch, max_abs_diff);
 }
 
 extern "C" int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms) {
