@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TTX_ABI_VERSION 3
+#define TTX_ABI_VERSION 4
 
 typedef enum ttx_status {
   TTX_OK = 0,
@@ -32,7 +32,8 @@ typedef enum ttx_status {
   TTX_ERR_NO_DEVICE = -3,    /* no gfx950 device visible: the library has NO CPU fallback         */
   TTX_ERR_REFERENCE = -4,    /* input on which the reference itself raises (see ttx_last_error)  */
   TTX_ERR_NOMEM = -5,
-  TTX_ERR_ROW_REPLAY = -6    /* ttx_greedy_speculative_generate_rows only: decode the batches as given instead */
+  TTX_ERR_ROW_REPLAY = -6,   /* ttx_greedy_speculative_generate_rows only: decode the batches as given instead */
+  TTX_ERR_MAX_STEPS = -7     /* beam-speculative: the ttx_beam_params.max_steps guard tripped (non-terminating input) */
 } ttx_status;
 
 /* Model hyper-parameters: the init_args of VanillaTransformer (src/model/modules.py:11-38). */
@@ -166,7 +167,9 @@ int ttx_ragged_topk(ttx_session* s, const float* d_score, const int32_t* d_offse
  *   d_src int64 [B, Ls];  d_out int64 [B, n_best, max_len] (row stride max_len): the reference's result tensor
  *   [B, n_best, W] occupies the first W = stats->out_width columns of every row (W <= max_len), hypotheses best first.
  * Errors: TTX_ERR_REFERENCE where the reference asserts/raises (fewer candidate leaves than n_best for a source, :195;
- * no drafts, drafting.py:39-43; max_len < 3); TTX_ERR_INVALID with "max_steps" in the text when the guard below trips. */
+ * no drafts, drafting.py:39-43; max_len < 3); TTX_ERR_MAX_STEPS when the guard below trips.
+ * Limits of the native loop (the reference has none; TTX_ERR_INVALID names the one exceeded): n_best <= 32, n_drafts <= 64,
+ * vocabulary <= 1024, n_best * (draft_len + 1) <= 1023 and 2 * n_best^2 * (draft_len + 1) * 4 bytes <= 150 KB of LDS. */
 typedef struct ttx_beam_params {
   int32_t max_len;
   int32_t n_best;            /* <= 32                                                                  */
@@ -200,6 +203,34 @@ int ttx_beam_speculative_generate(ttx_session* s, const int64_t* d_src, int B, i
  * them): per-batch outputs and stats are those of n_batches calls of ttx_beam_speculative_generate. */
 int ttx_beam_speculative_generate_many(ttx_session** sessions, int n_sessions, int n_batches, const int64_t* const* d_src,
                                        const int* B, const int* Ls, const ttx_beam_params* p, int64_t* const* d_out,
+                                       ttx_beam_stats* stats, void* stream);
+
+/* The same generator with continuous batching over the SOURCES of many given batches (SURVEY.md §8(f) #1 for the beam path).
+ * In the reference's loop the sources of a batch meet only in batch-wide scalars: the tensor width, the draft length
+ * min(max_len - longest row - 1, draft_len) (:476 / :671), the stop rule "every row holds EOS" (:586 / :826) and, in smart
+ * mode, the width of the -1-padded table the best draft is picked from (the batch's longest draft group, :779-784 -> :225).
+ * A source all of whose n_best rows hold EOS is a fixed point of the iteration.  This entry point therefore decodes every
+ * source under the rule it would see ALONE in a batch, in pools of `capacity` source slots per session that are refilled from
+ * the work list as sources finish (one verify step per iteration over all live candidates of a pool), and returns per source
+ *   d_out        int64 [R_total][n_best][max_len]  hypotheses best first, PAD beyond (written when the source finished)
+ *   d_trace_len  int16 [R_total][trace_cap]        longest hypothesis after each of the source's iterations (-1 past the last)
+ *   d_trace_grp  uint8 [R_total][trace_cap]        smart mode: bits 0-6 the source's longest draft group of that iteration,
+ *                                                  bit 7 set when a wider table (up to n_drafts) would pick another draft
+ *   d_summary    int32 [R_total][8]                iterations, status (1 finished, 2 fewer leaves than n_best: the reference
+ *                                                  asserts, 3 a row came within draft_len + 1 of max_len: decode the batch as
+ *                                                  given, 4 max_steps, 5 more than trace_cap iterations), input lines, running
+ *                                                  rows, accepted-token sum, accepted count, longest hypothesis, decoded
+ *                                                  candidates summed over the iterations
+ * from which a caller replays the reference's loop over the batches AS GIVEN (translation-transformer_amd/scheduling.py
+ * replay_beam_batch: result width, model calls, counters; batches whose scalars would have coupled their sources are decoded
+ * again with ttx_beam_speculative_generate_many).  d_src int64 [R_total][Ls_all] all sources right-padded, in admission order;
+ * h_len / h_given_ls (HOST, int32 [R_total]): a source's length (position after its last non-PAD token) and the padded width
+ * of the batch it was given in (smart mode builds its window library over that width, :603-615).  `stats` receives the sums of
+ * what the device executed (model_calls = iterations of all pools).  TTX_ERR_INVALID when max_len - 2 < draft_len (the very
+ * first draft would be cut: decode as given). */
+int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_sessions, const int64_t* d_src, int R_total, int Ls_all,
+                                       const int32_t* h_len, const int32_t* h_given_ls, int capacity, const ttx_beam_params* p,
+                                       int64_t* d_out, int16_t* d_trace_len, uint8_t* d_trace_grp, int32_t* d_summary, int trace_cap,
                                        ttx_beam_stats* stats, void* stream);
 
 /* TranslationInferenceBeamSearch.generate (src/decoding/standard_decoding.py:89-174) — the whole loop on the device with a
@@ -291,9 +322,11 @@ int ttx_debug_step_snapshot(ttx_session* s, int32_t* info, float* h_logits, int3
  * TTX_PROFILE_GEMM=1 in the environment (that session launches eagerly, without graphs). */
 int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms);
 
-/* Development aid (tools/bench_gemm.py): times one GEMM shape in isolation on random operands.  variant 2 / 3 / 4 =
- * the 64x64, 32x32 and 128x128 kernels; splits 0 = fused bias epilogue, > 0 = split-K slabs.  Returns microseconds
- * per launch over `reps` back-to-back launches and the largest absolute difference to the 64x64 kernel's result. */
+/* Development aid (tools/bench_gemm.py): times one GEMM shape (K = 64, 128 or a multiple of 256) in isolation on random
+ * operands.  variant 2 / 46 / 4 = 64x64, 128x64, 128x128 tiles; 24 = the production kernel's own choice from the row count;
+ * 3 = one wave per canonical slice (32x32 tiles, K = 256); 8 = one workgroup per slice with `splits` raw slabs (FFN2).  Returns
+ * microseconds per launch over `reps` back-to-back launches and the largest absolute difference to the 64x64 tiling's result
+ * — 0.0 for every variant: all of them evaluate the same ordered sum of K slices (csrc/ttx_gemm.hip). */
 int ttx_debug_gemm_bench(ttx_session* s, int M, int N, int K, int splits, int variant, int reps, double* us_per_launch,
                          double* max_abs_diff);
 

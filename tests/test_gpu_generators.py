@@ -23,29 +23,9 @@ def tiny(tta):
 
 
 @pytest.fixture(scope="module")
-def full_state_trained():
-    """Full-size weights overfit on the 10 fixture pairs (stock torch training on the GPU: set-up only)."""
-    import sys
-    from pathlib import Path
-    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-    from tools.train_synth import TrainModel
-    src, tgt, _, V = fixture_tokens()
-    torch.manual_seed(1234)
-    model = TrainModel(vocab=V).cuda()
-    opt = torch.optim.Adam(model.parameters(), lr=3e-4)
-    crit = torch.nn.CrossEntropyLoss()
-    s, t = src.cuda(), tgt.cuda()
-    model.train()
-    for step in range(600):
-        loss = crit(model(s, t[:, :-1]).reshape(-1, V), t[:, 1:].reshape(-1))
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        if loss.item() < 5e-3:
-            break
-    print("full-size fixture model: steps", step, "loss", loss.item())
-    assert loss.item() < 0.05
-    return {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+def full_state_trained(trained_full_state):
+    """Full-size 4+4 weights overfit on the 10 fixture pairs (trained once per session: tests/conftest.py)."""
+    return trained_full_state(4)
 
 
 @pytest.fixture(scope="module")

@@ -23,6 +23,7 @@ OBJ_DIR = CSRC / "build"
 
 TTX_OK, TTX_ERR_INVALID, TTX_ERR_HIP, TTX_ERR_NO_DEVICE, TTX_ERR_REFERENCE, TTX_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 TTX_ERR_ROW_REPLAY = -6
+TTX_ERR_MAX_STEPS = -7
 
 
 class TtxError(RuntimeError):
@@ -112,6 +113,8 @@ SYMBOLS = {
     "ttx_beam_speculative_generate_many": (C.c_int, [C.POINTER(_VP), _I, _I, C.POINTER(_VP), C.POINTER(C.c_int),
                                                     C.POINTER(C.c_int), C.POINTER(BeamParams), C.POINTER(_VP),
                                                     C.POINTER(BeamStats), _VP]),
+    "ttx_beam_speculative_generate_pool": (C.c_int, [C.POINTER(_VP), _I, _VP, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I,
+                                                    C.POINTER(BeamParams), _VP, _VP, _VP, _VP, _I, C.POINTER(BeamStats), _VP]),
     "ttx_beam_generate": (C.c_int, [_VP, _VP, _I, _I, C.POINTER(BeamSearchParams), _VP, C.POINTER(BeamSearchStats), _VP]),
     "ttx_nucleus_mask": (C.c_int, [_VP, _VP, _I, _I, C.c_float, _I, C.c_float, _VP, _VP]),
     "ttx_accepted_lengths": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _I, _VP, _VP]),
@@ -184,7 +187,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if handle.ttx_abi_version() != 3:
+    if handle.ttx_abi_version() != 4:
         raise RuntimeError("libttx_hip.so ABI version mismatch")
     _lib = handle
     return _lib
@@ -196,4 +199,6 @@ def check(code: int) -> None:
     msg = lib().ttx_last_error().decode("utf-8", "replace")
     if code == TTX_ERR_REFERENCE:
         raise ReferenceError_(msg)
+    if code == TTX_ERR_MAX_STEPS:
+        raise RuntimeError("beam-speculative loop exceeded max_steps (non-terminating input)")
     raise TtxError(code, msg)

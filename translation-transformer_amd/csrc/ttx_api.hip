@@ -1691,7 +1691,7 @@ static bool beam_after_iter(BeamJob& j) {
   j.room = j.p.max_len - j.after_last - 1;
   if (!(j.room >= 1 && j.after_last <= j.p.max_len)) return false;  // :464
   if (j.p.max_steps > 0 && j.launched >= j.p.max_steps) {
-    j.rc = fail(TTX_ERR_INVALID, "beam-speculative loop exceeded max_steps (non-terminating input)");
+    j.rc = fail(TTX_ERR_MAX_STEPS, "beam-speculative loop exceeded max_steps (non-terminating input)");
     return false;
   }
   return true;
@@ -1806,6 +1806,383 @@ extern "C" int ttx_beam_speculative_generate(ttx_session* s, const int64_t* d_sr
   if (!s) return fail(TTX_ERR_INVALID, "null session");
   const int rc = ttx_beam_speculative_generate_many(ss, 1, 1, srcs, &B, &Ls, p, outs, stats ? stats : &local, stream);
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Beam-speculative source pool (kernels and the argument for exactness: "Beam-speculative SOURCE POOL" in
+// ttx_loop_kernels.hip.h).  Host side: one job per session, each a pool of C source slots fed from the caller's work list;
+// an iteration is one fixed launch sequence (captured once per cache parity and GEMM variant) over every live candidate.
+struct BeamPoolJob {
+  ttx_session* s = nullptr;
+  hipStream_t st = nullptr;
+  ttx_beam_params p{};
+  int C = 0, K = 0, N = 0, D0 = 0, lib_ld = 0, Ls_cap = 0, gen_ld = 0, Lc = 0, MC = 0;
+  bool smart = false;
+  BeamPoolArgs a{};
+  BeamPoolIo io{};
+  int launched = 0, cur = 0;
+  int phase = 0;                    // 0 not started, 1 running, 2 finishing, 3 done
+  int admitted_since = 0;           // sources admitted since the last published iteration
+  long long src_tokens_padded = 0, admitted_rows = 0;
+  unsigned idle_spins = 0;
+  std::chrono::steady_clock::time_point last_progress = std::chrono::steady_clock::now();
+};
+
+static int bpool_start(BeamPoolJob& j, ttx_session* s, hipStream_t st, int C, int Ls_cap, const ttx_beam_params* p, const BeamPoolIo& io_host,
+                       const int32_t* h_len, const int32_t* h_given, int R_total) {
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
+  j = BeamPoolJob{};
+  j.s = s; j.st = st; j.p = *p; j.C = C; j.K = p->n_best; j.N = p->n_drafts; j.smart = p->smart_drafts_mode != 0; j.Ls_cap = Ls_cap;
+  const int Dreq = clamp_draft_len(p->draft_len, 5, 200);
+  j.lib_ld = clamp_draft_len(Dreq + 1, 5, 200);
+  j.D0 = j.smart ? j.lib_ld - 1 : Dreq;
+  j.gen_ld = p->max_len + j.D0 + 2;
+  j.Lc = p->max_len + j.D0 + 2;
+  j.MC = C * j.K;
+  const size_t MC = (size_t)j.MC;
+  const size_t Mmax = MC * step_rps(j.N, j.D0);
+  const size_t kv_row = (size_t)Ld * 2 * d;
+  int rc = TTX_OK;
+  auto need = [&](Buf& b, size_t bytes) { if (rc == TTX_OK) rc = ensure(b, bytes, st); };
+  need(s->tok_src, (size_t)C * Ls_cap * 4); need(s->valid_new, (size_t)C * Ls_cap); need(s->src_valid, (size_t)C * Ls_cap);
+  need(s->memory, (size_t)C * Ls_cap * d * 4); need(s->memkv_new, (size_t)C * Ls_cap * kv_row * 4); need(s->memkv, (size_t)C * Ls_cap * kv_row * 4);
+  need(s->bp_tok, (size_t)C * Ls_cap * 4);
+  need(s->drafts_new, (size_t)C * j.N * j.D0 * 4); need(s->bs_drafts_src, (size_t)C * j.N * j.D0 * 4);
+  need(s->drafts, MC * j.N * j.D0 * 4);
+  need(s->gen, MC * j.gen_ld * 4); need(s->front, MC * 4); need(s->act_idx, MC * 4);
+  need(s->pred, Mmax * 4); need(s->state, sizeof(DecState)); need(s->logits, Mmax * V * 4);
+  for (int i = 0; i < 2; ++i) { need(s->tk[i], (size_t)Ld * MC * j.Lc * d * 4); need(s->tv[i], (size_t)Ld * MC * j.Lc * d * 4); }
+  need(s->t_prev_len, MC * 4); need(s->t_slot_of, MC * 4); need(s->t_src_of, MC * 4); need(s->bp_cand_len, MC * 4);
+  need(s->bs_cand_next, MC * j.gen_ld * 8); need(s->bs_len_next, MC * 4); need(s->bs_fin_next, MC); need(s->bs_logp_next, MC * 4);
+  need(s->bs_len, MC * 4); need(s->bs_fin, MC); need(s->bs_active, MC); need(s->bs_logp, MC * 4); need(s->bs_per_cand, MC * 4);
+  need(s->bs_best_n, MC * 4); need(s->bs_best_slot, MC * 4); need(s->bs_chosen, MC * j.D0 * 8);
+  need(s->bs_hit, MC * (size_t)j.N * j.D0); need(s->bs_mark, MC);            // bs_mark: the live flags of the pool
+  need(s->bs_parent, MC * 4); need(s->bs_parent_draft, MC * 4); need(s->bp_sens, MC);
+  need(s->bs_cnt, sizeof(BeamCounters));
+  const size_t dl1 = (size_t)j.D0 + 1;
+  need(s->leaf_score, MC * dl1 * j.K * 4); need(s->leaf_tok, MC * dl1 * j.K * 4); need(s->leaf_cnt, MC * dl1 * 4);
+  need(s->beam_summary, 8 * 4); need(s->bp_grp, 4 * 4);
+  need(s->bp_row_of, (size_t)C * 4); need(s->bp_iter, (size_t)C * 4); need(s->bp_given_ls, (size_t)C * 4); need(s->bp_src_acc, (size_t)C * 32);
+  need(s->bp_new_slot, (size_t)C * 4);
+  need(s->bp_io, sizeof(BeamPoolIo) + (size_t)R_total * 8);
+  const size_t Macts = std::max(Mmax, (size_t)C * Ls_cap);
+  if (rc == TTX_OK) rc = ensure_acts(s, st, Macts, 1);
+  need(s->qkv, std::max((size_t)Ld * Mmax, (size_t)C * Ls_cap) * 3 * d * 4);
+  need(s->slab, sizeof(float) * 16 * Macts * d);
+  s->graphs_current();
+  TTX_TRY(rc);
+  if ((size_t)j.K * dl1 > 1023 || 2 * (size_t)j.K * dl1 * j.K * 4 > 150 * 1024)
+    return fail(TTX_ERR_INVALID, "too many leaves per source for the selection kernel's LDS image");
+  if (!s->bp_host) {
+    if (hipHostMalloc((void**)&s->bp_host, sizeof(BeamPoolHost), hipHostMallocMapped) != hipSuccess)
+      return fail(TTX_ERR_NOMEM, "hipHostMalloc failed");
+  }
+  std::memset(s->bp_host, 0, sizeof(BeamPoolHost));
+  BeamPoolHost* dev_host = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&dev_host, (void*)s->bp_host, 0));
+  s->ev_used = 0;
+  HIP_TRY(hipEventRecord(s->ev_a, st));
+  // the caller-side pointer block and the per-source lengths live in one device allocation: [BeamPoolIo][len_all][given_all]
+  char* io_dev = s->bp_io.as<char>();
+  int* len_dev = reinterpret_cast<int*>(io_dev + sizeof(BeamPoolIo));
+  int* given_dev = len_dev + R_total;
+  j.io = io_host;
+  j.io.len_all = len_dev; j.io.given_all = given_dev;
+  HIP_TRY(hipMemcpyAsync(io_dev, &j.io, sizeof(BeamPoolIo), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(len_dev, h_len, (size_t)R_total * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(given_dev, h_given, (size_t)R_total * 4, hipMemcpyHostToDevice, st));
+  BeamPoolArgs& a = j.a;
+  a.C = C; a.K = j.K; a.N = j.N; a.D0 = j.D0; a.Ls_cap = Ls_cap; a.max_len = p->max_len; a.ld = j.gen_ld;
+  a.smart = j.smart ? 1 : 0; a.lib_ld = j.lib_ld; a.pad = p->pad_token; a.bos = p->bos_token; a.eos = p->eos_token; a.repl = p->replace_token;
+  a.max_steps = p->max_steps;
+  a.row_of = s->bp_row_of.as<int>(); a.iter = s->bp_iter.as<int>(); a.given_ls = s->bp_given_ls.as<int>(); a.src_acc = s->bp_src_acc.as<int>();
+  a.tok = s->bp_tok.as<int>(); a.drafts_all = s->bs_drafts_src.as<int>();
+  a.cand_next = s->bs_cand_next.as<int64_t>(); a.len_next = s->bs_len_next.as<int>(); a.fin_next = s->bs_fin_next.as<uint8_t>();
+  a.logp_next = s->bs_logp_next.as<float>(); a.parent = s->bs_parent.as<int>(); a.parent_draft = s->bs_parent_draft.as<int>();
+  a.gen = s->gen.as<int>(); a.front = s->front.as<int>(); a.len = s->bs_len.as<int>(); a.active = s->bs_active.as<uint8_t>();
+  a.finished = s->bs_fin.as<uint8_t>(); a.live = s->bs_mark.as<uint8_t>(); a.logp = s->bs_logp.as<float>(); a.per_cand = s->bs_per_cand.as<int>();
+  a.drafts32 = s->drafts.as<int>();
+  a.sens = j.smart ? s->bp_sens.as<uint8_t>() : nullptr; a.chosen_slot = s->bs_best_slot.as<int>(); a.chosen = s->bs_chosen.as<int64_t>();
+  a.leaf_score = s->leaf_score.as<float>(); a.leaf_tok = s->leaf_tok.as<int>(); a.leaf_cnt = s->leaf_cnt.as<int>();
+  a.cnt = s->bs_cnt.as<BeamCounters>(); a.io = reinterpret_cast<const BeamPoolIo*>(io_dev); a.host = dev_host; a.dev_summary = s->bp_grp.as<int>();
+  hipLaunchKernelGGL(k_bsp_init, dim3(64), dim3(256), 0, st, a, s->t_src_of.as<int>(), s->bp_cand_len.as<int>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev_b, st));
+  j.phase = 1;
+  return TTX_OK;
+}
+
+// Encode R new sources (rows first_row .. of the caller's matrix, Ls_new columns of it) and hand them free source slots.
+static int bpool_admit(BeamPoolJob& j, const int64_t* d_src_rows, int ld_src, int R, int Ls_new, int first_row) {
+  ttx_session* s = j.s;
+  hipStream_t st = j.st;
+  const ttx_model* m = s->m;
+  const ttx_config& c = m->cfg;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers;
+  const int kv_row = Ld * 2 * d;
+  hipLaunchKernelGGL(k_prepare_tokens_2d, dim3(cdiv(R * Ls_new, 256)), dim3(256), 0, st, d_src_rows, ld_src, s->tok_src.as<int>(),
+                     s->valid_new.as<uint8_t>(), R, Ls_new, c.pad_token);
+  HIP_TRY(hipGetLastError());
+  TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->valid_new.as<uint8_t>(), R, Ls_new, s->memory.as<float>()));
+  const int gv = variant_for_rows(s, (long long)R * Ls_new, false);
+  TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv_new.as<float>(),
+                      kv_row, nullptr, R * Ls_new, kv_row, d, false, 0, 0, gv));
+  if (!j.smart)      // make_drafts(src[:, 1:], draft_len, N, 5, 200) (:430): independent of how far the row is padded
+    TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls_new, 1, R, Ls_new - 1, j.N, j.D0, j.p.eos_token, j.p.pad_token,
+                                    j.p.replace_token, s->drafts_new.as<int>()));
+  hipLaunchKernelGGL(k_bsp_admit, dim3(1), dim3(64), 0, st, j.a, s->bp_new_slot.as<int>(), s->bp_cand_len.as<int>(), R, first_row);
+  HIP_TRY(hipGetLastError());
+  BeamPoolFillArgs f{};
+  f.new_slot = s->bp_new_slot.as<int>(); f.R = R; f.first_row = first_row;
+  f.C = j.C; f.K = j.K; f.N = j.N; f.D0 = j.D0; f.ld = j.gen_ld; f.Ls_cap = j.Ls_cap; f.Ls_new = Ls_new; f.max_len = j.p.max_len;
+  f.pad = j.p.pad_token; f.bos = j.p.bos_token;
+  f.cand_next = j.a.cand_next; f.len_next = j.a.len_next; f.fin_next = j.a.fin_next; f.logp_next = j.a.logp_next; f.parent = j.a.parent;
+  f.parent_draft = j.a.parent_draft;
+  f.tok = s->bp_tok.as<int>(); f.tok_new = s->tok_src.as<int>(); f.src_valid = s->src_valid.as<uint8_t>(); f.valid_new = s->valid_new.as<uint8_t>();
+  f.drafts_all = s->bs_drafts_src.as<int>(); f.drafts_new = j.smart ? nullptr : s->drafts_new.as<int>();
+  f.memkv = s->memkv.as<float>(); f.memkv_new = s->memkv_new.as<float>(); f.kv_row = kv_row; f.io = j.a.io;
+  hipLaunchKernelGGL(k_bsp_fill, dim3(R, 1 + Ls_new), dim3(256), 0, st, f);
+  HIP_TRY(hipGetLastError());
+  j.admitted_rows += R;
+  j.admitted_since += R;
+  j.src_tokens_padded += (long long)R * Ls_new;
+  return TTX_OK;
+}
+
+static int bpool_enqueue_iter(const BeamPoolJob& j, int cur, int variant) {
+  ttx_session* s = j.s;
+  hipStream_t st = j.st;
+  const ttx_config& c = s->m->cfg;
+  const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
+  const int dl = j.D0, MC = j.MC;
+  const long long cache_seq = (long long)j.Lc * d, cache_layer = (long long)MC * cache_seq;
+  hipLaunchKernelGGL(k_bsp_prep, dim3(MC), dim3(256), 0, st, j.a);
+  HIP_TRY(hipGetLastError());
+  const int nxt = cur ^ 1;
+  TreeCacheArgs ca{};
+  ca.len = s->bs_len.as<int>(); ca.parent = s->bs_parent.as<int>(); ca.parent_draft = s->bs_parent_draft.as<int>();
+  ca.prev_len = s->t_prev_len.as<int>(); ca.active = s->bs_active.as<uint8_t>();
+  ca.k_old = s->tk[cur].as<float>(); ca.v_old = s->tv[cur].as<float>(); ca.k_new = s->tk[nxt].as<float>(); ca.v_new = s->tv[nxt].as<float>();
+  ca.cache_layer_stride = cache_layer; ca.cache_seq_stride = cache_seq;
+  ca.qkv_prev = s->qkv.as<float>(); ca.qkv_layer_stride = (long long)MC * step_rps(j.N, dl) * 3 * d;
+  ca.prev_slot_of = s->t_slot_of.as<int>(); ca.prev_N = j.N; ca.prev_D = dl; ca.d = d;
+  hipLaunchKernelGGL(k_tree_cache, dim3(MC, Ld), dim3(256), 0, st, ca);      // fresh candidates (parent -1) have nothing to inherit
+  HIP_TRY(hipGetLastError());
+  BeamListArgs la{};
+  la.active = s->bs_active.as<uint8_t>(); la.per_cand = s->bs_per_cand.as<int>(); la.len = s->bs_len.as<int>();
+  la.n_cand = MC; la.N = j.N; la.dl = dl;
+  la.act_idx = s->act_idx.as<int>(); la.slot_of = s->t_slot_of.as<int>(); la.prev_len = s->t_prev_len.as<int>();
+  la.st = s->state.as<DecState>(); la.cnt = s->bs_cnt.as<BeamCounters>(); la.summary = s->beam_summary.as<int>();
+  hipLaunchKernelGGL(k_bs_list, dim3(1), dim3(256), 0, st, la);
+  HIP_TRY(hipGetLastError());
+  StepCtx k{};
+  k.B = MC; k.Ls = j.Ls_cap; k.N = j.N; k.D = dl; k.Lc = j.Lc; k.gen_ld = j.gen_ld; k.max_len = j.p.max_len;
+  k.kcache = s->tk[nxt].as<float>(); k.vcache = s->tv[nxt].as<float>(); k.src_of = s->t_src_of.as<int>(); k.src_len = s->bp_cand_len.as<int>();
+  k.want_argmax = false; k.variant = variant;
+  TTX_TRY(run_step(s, st, k, std::min(j.p.max_len, ((j.p.max_len + 63) / 64) * 64)));
+  BeamHitsArgs ha{};
+  ha.logits = s->logits.as<float>(); ha.V = V; ha.finished = s->bs_fin.as<uint8_t>(); ha.slot_of = s->t_slot_of.as<int>();
+  ha.per_cand = s->bs_per_cand.as<int>(); ha.drafts32 = s->drafts.as<int>();
+  ha.n_cand = MC; ha.N = j.N; ha.dl = dl; ha.K = j.K; ha.nucleus = 0.9975f; ha.hit = s->bs_hit.as<uint8_t>();
+  BeamLeaves2Args le{};
+  le.logits = s->logits.as<float>(); le.V = V; le.finished = s->bs_fin.as<uint8_t>(); le.slot_of = s->t_slot_of.as<int>();
+  le.per_cand = s->bs_per_cand.as<int>(); le.drafts32 = s->drafts.as<int>(); le.logp = s->bs_logp.as<float>();
+  le.hit = s->bs_hit.as<uint8_t>(); le.cnt = s->bs_cnt.as<BeamCounters>();
+  le.n_cand = MC; le.N = j.N; le.dl = dl; le.K = j.K; le.bos = j.p.bos_token; le.pad = j.p.pad_token; le.smart = j.smart ? 1 : 0;
+  le.best_n = s->bs_best_n.as<int>(); le.best_slot = s->bs_best_slot.as<int>(); le.chosen = s->bs_chosen.as<int64_t>();
+  le.leaf_score = s->leaf_score.as<float>(); le.leaf_tok = s->leaf_tok.as<int>(); le.leaf_cnt = s->leaf_cnt.as<int>();
+  le.live = s->bs_mark.as<uint8_t>(); le.pool_K = j.K; le.sens = j.smart ? s->bp_sens.as<uint8_t>() : nullptr;
+  const dim3 hits_grid(MC, cdiv(std::max(j.N * dl, 1), BS_HITS_WAVES));
+  const size_t leaves_lds = (size_t)2 * (dl + 1) * 4;
+  if (V <= 256) {
+    hipLaunchKernelGGL(k_bs_hits<4>, hits_grid, dim3(BS_HITS_WAVES * 64), 0, st, ha);
+    hipLaunchKernelGGL(k_bs_leaves<4>, dim3(MC), dim3(BS_LEAVES_THREADS), leaves_lds, st, le);
+  } else if (V <= 512) {
+    hipLaunchKernelGGL(k_bs_hits<8>, hits_grid, dim3(BS_HITS_WAVES * 64), 0, st, ha);
+    hipLaunchKernelGGL(k_bs_leaves<8>, dim3(MC), dim3(BS_LEAVES_THREADS), leaves_lds, st, le);
+  } else {
+    hipLaunchKernelGGL(k_bs_hits<NUC_VPL>, hits_grid, dim3(BS_HITS_WAVES * 64), 0, st, ha);
+    hipLaunchKernelGGL(k_bs_leaves<NUC_VPL>, dim3(MC), dim3(BS_LEAVES_THREADS), leaves_lds, st, le);
+  }
+  HIP_TRY(hipGetLastError());
+  const size_t lds = 2 * (size_t)j.K * (dl + 1) * j.K * 4;
+  if (lds > 64 * 1024 && !s->attr_pool_select) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bsp_select), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    s->attr_pool_select = true;
+  }
+  hipLaunchKernelGGL(k_bsp_select, dim3(j.C), dim3(256), lds, st, j.a);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_bsp_publish, dim3(1), dim3(64), 0, st, j.a);
+  HIP_TRY(hipGetLastError());
+  return TTX_OK;
+}
+
+static int bpool_launch_iter(BeamPoolJob& j, int n_running) {
+  ttx_session* s = j.s;
+  const int cur = j.cur;
+  const int variant = variant_for_rows(s, (long long)std::max(1, n_running) * step_rps(j.N, j.D0), true);
+  int rc = TTX_OK;
+  if (!s->use_graphs || s->profile) {
+    rc = bpool_enqueue_iter(j, cur, variant);
+  } else {
+    s->graphs_current();
+    const std::vector<int> key{-7, j.C, j.Ls_cap, j.K, j.N, j.D0, j.smart ? 1 : 0, j.p.max_len, cur, variant, j.p.pad_token, j.p.bos_token,
+                               j.p.eos_token, j.p.replace_token, j.p.max_steps};
+    auto it = s->beam_graphs.find(key);
+    if (it == s->beam_graphs.end() && !s->beam_warmed.count(key)) {
+      s->beam_warmed.insert(key);                  // first use runs eagerly: function attributes are set outside capture
+      rc = bpool_enqueue_iter(j, cur, variant);
+    } else {
+      if (it == s->beam_graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(hipStreamBeginCapture(j.st, hipStreamCaptureModeThreadLocal));
+        rc = bpool_enqueue_iter(j, cur, variant);
+        hipError_t e = hipStreamEndCapture(j.st, &graph);
+        if (rc != TTX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return fail(TTX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return fail(TTX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        if (s->beam_graphs.size() > 256) s->drop_graphs();
+        it = s->beam_graphs.emplace(key, exec).first;
+      }
+      HIP_TRY(hipGraphLaunch(it->second, j.st));
+    }
+  }
+  TTX_TRY(rc);
+  ++j.launched;
+  j.cur = cur ^ 1;
+  j.admitted_since = 0;
+  j.last_progress = std::chrono::steady_clock::now();
+  j.idle_spins = 0;
+  return TTX_OK;
+}
+
+extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_sessions, const int64_t* d_src, int R_total, int Ls_all,
+                                                  const int32_t* h_len, const int32_t* h_given_ls, int capacity,
+                                                  const ttx_beam_params* p, int64_t* d_out, int16_t* d_trace_len, uint8_t* d_trace_grp,
+                                                  int32_t* d_summary, int trace_cap, ttx_beam_stats* stats, void* stream) {
+  if (!sessions || n_sessions <= 0 || !d_src || R_total < 0 || !h_len || !h_given_ls || capacity <= 0 || capacity > 1024 || !p || !d_out ||
+      !d_trace_len || !d_trace_grp || !d_summary || trace_cap <= 0 || trace_cap > 32000 || !stats)
+    return fail(TTX_ERR_INVALID, "bad argument to ttx_beam_speculative_generate_pool");
+  if (R_total == 0) return TTX_OK;
+  for (int i = 0; i < n_sessions; ++i) { if (!sessions[i]) return fail(TTX_ERR_INVALID, "null session"); TTX_TRY(session_alive(sessions[i])); }
+  int len_max = 2;
+  for (int i = 0; i < R_total; ++i) {
+    if (h_len[i] < 2 || h_len[i] > Ls_all) return fail(TTX_ERR_INVALID, "row length outside [2, width of the source matrix]");
+    if (h_given_ls[i] < h_len[i]) return fail(TTX_ERR_INVALID, "a source's given batch width is smaller than its length");
+    if (p->smart_drafts_mode && h_given_ls[i] - 5 <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
+    len_max = std::max(len_max, (int)h_len[i]);
+  }
+  const ttx_config& c = sessions[0]->m->cfg;
+  int Ls_cap = std::min(std::max(192, ((len_max + 63) / 64) * 64), c.max_positions);
+  Ls_cap = std::max(Ls_cap, len_max);
+  TTX_TRY(beam_validate(sessions[0], d_src, 1, Ls_cap, p, d_out));
+  const int Dreq = clamp_draft_len(p->draft_len, 5, 200);
+  const int D0 = p->smart_drafts_mode ? clamp_draft_len(Dreq + 1, 5, 200) - 1 : Dreq;
+  if (p->max_len - 2 < D0)       // the very first draft would be cut (:476): the per-source rule of the pool does not apply
+    return fail(TTX_ERR_INVALID, "the source pool needs max_len - 2 >= draft_len; decode the batches as given");
+  HIP_TRY(hipSetDevice(sessions[0]->m->device));
+  release_retired();
+  EventGuard ready;
+  HIP_TRY(hipEventCreateWithFlags(&ready.e, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ready.e, (hipStream_t)stream));
+  const int n_jobs = std::min(n_sessions, cdiv(R_total, std::max(1, std::min(capacity / 2, 8))));
+  const int C = std::min(capacity, std::max(1, cdiv(R_total, n_jobs)));
+  BeamPoolIo io{};
+  io.out = d_out; io.trace_len = d_trace_len; io.trace_grp = d_trace_grp; io.summary = d_summary; io.T_cap = trace_cap;
+  std::vector<BeamPoolJob> jobs(n_jobs);
+  int rc_final = TTX_OK;
+  for (int i = 0; i < n_jobs && rc_final == TTX_OK; ++i) {
+    ttx_session* s = sessions[i];
+    if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamWaitEvent(s->own_stream, ready.e, 0));
+    rc_final = bpool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, io, h_len, h_given_ls, R_total);
+  }
+  int admit_div = 4;
+  if (const char* e = getenv("TTX_POOL_ADMIT_DIV")) admit_div = std::max(1, atoi(e));
+  const int min_admit = std::max(1, C / admit_div);
+  int cursor = 0, done = 0;
+  bool hung = false;
+  ttx_beam_stats acc{};
+  while (done < n_jobs && rc_final == TTX_OK) {
+    bool progressed = false;
+    for (int i = 0; i < n_jobs && rc_final == TTX_OK; ++i) {
+      BeamPoolJob& j = jobs[i];
+      ttx_session* s = j.s;
+      volatile BeamPoolHost* bh = s->bp_host;
+      if (j.phase == 1) {
+        if (j.launched > 0 && bh->steps_done < j.launched) {                  // the iteration in flight has not published yet
+          if ((++j.idle_spins & 0xffff) == 0 && watchdog_expired(j.last_progress)) { rc_final = session_hung(s); hung = true; break; }
+          continue;
+        }
+        if (bh->error) { rc_final = fail(TTX_ERR_HIP, "source pool bookkeeping failed (admitted more sources than free slots)"); break; }
+        int n_live = (j.launched == 0 ? 0 : bh->n_live) + j.admitted_since;
+        int n_running = (j.launched == 0 ? 0 : bh->n_running) + j.admitted_since;
+        const int free_slots = C - n_live;
+        if (cursor < R_total && (n_live == 0 || free_slots >= min_admit)) {
+          // the last sources of the list are shared out over the pools still running, so that they drain together
+          int n_run_jobs = 0;
+          for (const BeamPoolJob& o : jobs) n_run_jobs += (o.phase == 1);
+          const int remaining = R_total - cursor;
+          int share = std::max(1, cdiv(remaining, std::max(1, n_run_jobs)));
+          if (j.launched == 0 && (long long)n_jobs * C >= R_total) share = std::max(1, cdiv(remaining, n_jobs - i));
+          const int take = std::min({free_slots, remaining, share});
+          int Ls_new = 2;
+          for (int r = cursor; r < cursor + take; ++r) Ls_new = std::max(Ls_new, (int)h_len[r]);
+          rc_final = bpool_admit(j, d_src + (size_t)cursor * Ls_all, Ls_all, take, Ls_new, cursor);
+          if (rc_final != TTX_OK) break;
+          cursor += take;
+          n_live += take;
+          n_running += take;
+        }
+        if (n_live == 0) {
+          if (hipEventRecord(s->ev_c, j.st) != hipSuccess ||
+              hipMemcpyAsync(s->host_state, s->bs_cnt.p, sizeof(BeamCounters), hipMemcpyDeviceToHost, j.st) != hipSuccess ||
+              hipEventRecord(s->ev_done, j.st) != hipSuccess) {
+            rc_final = fail(TTX_ERR_HIP, "source pool: enqueueing the final counter read-back failed");
+            break;
+          }
+          j.phase = 2;
+        } else {
+          if (j.launched > (long long)(trace_cap + 2) * (R_total + 1)) { rc_final = fail(TTX_ERR_HIP, "source pool failed to terminate"); break; }
+          rc_final = bpool_launch_iter(j, n_running);
+        }
+        progressed = true;
+      } else if (j.phase == 2) {
+        if (hipEventQuery(s->ev_done) == hipSuccess) {
+          const BeamCounters* cn = reinterpret_cast<const BeamCounters*>(s->host_state);
+          acc.model_calls += cn->model_calls;
+          acc.input_lines += cn->input_lines;
+          acc.running_rows += cn->running_rows;
+          acc.verified_positions += cn->verified_positions;
+          acc.executed_positions += cn->executed_positions;
+          acc.kv_prefix_positions += cn->kv_prefix_positions;
+          acc.running_candidates += cn->running_cands;
+          acc.src_tokens_padded += j.src_tokens_padded;
+          float ms = 0.f;
+          if (hipEventElapsedTime(&ms, s->ev_a, s->ev_c) == hipSuccess) acc.decode_ms += ms;
+          collect_gemm_profile(s, j.st);
+          j.phase = 3;
+          ++done;
+          progressed = true;
+        }
+      }
+    }
+    if (!progressed) __builtin_ia32_pause();
+  }
+  if (hung) {
+    for (int i = 0; i < n_jobs; ++i) jobs[i].s->dead = true;
+  } else {
+    for (int i = 0; i < n_jobs; ++i)
+      if (jobs[i].s && jobs[i].s->own_stream) (void)hipStreamSynchronize(jobs[i].s->own_stream);
+  }
+  acc.status = rc_final;
+  *stats = acc;
+  return rc_final;
 }
 
 // ------------------------------------------------------------------------------------------------

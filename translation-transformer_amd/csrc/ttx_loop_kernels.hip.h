@@ -750,17 +750,18 @@ struct BeamSelectArgs {
   int* new_len; uint8_t* new_finished;         // optional [B*K]: real tokens of every new row / whether it holds EOS
 };
 
-template <typename TokT>
-__global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
-  extern __shared__ float sh[];                // scores [L] then codes [L] (as int)
-  const int b = blockIdx.x;
-  const int dl1 = a.dl + 1;
-  const int L = a.beam * dl1 * a.K;            // strided capacity; entries beyond a (c,p) count hold -inf
+// The K best leaves among the `nseg` (candidate, position) segments starting at segment `seg0` (each segment holds up to K
+// leaves in leaf_score / leaf_tok, `leaf_cnt[seg]` of them real), best first: s_win[r] = index of the r-th best as
+// local_segment * K + i, s_wsc[r] its score.  Order: higher score first, equal scores by enumeration order.  Returns false
+// when there are fewer than K leaves (the reference asserts there, speculative_decoding.py:195).  Whole 256-thread workgroup;
+// `sh` = 2 * nseg * K floats of dynamic LDS.
+__device__ __forceinline__ bool select_best_leaves(const float* leaf_score, const int* leaf_cnt, size_t seg0, int nseg, int K, float* sh,
+                                                   int* s_win, float* s_wsc) {
+  const int L = nseg * K;                      // strided capacity; entries beyond a segment's count hold -inf
   float* sc = sh;
-  int* code = reinterpret_cast<int*>(sh + L);  // enumeration rank of each strided entry (for tie-breaking) or -1
-  __shared__ int s_off[1024];                  // exclusive prefix of leaf counts over (candidate, position) of this source
-  const int nseg = a.beam * dl1;
-  for (int sidx = threadIdx.x; sidx < nseg; sidx += blockDim.x) s_off[sidx] = a.leaf_cnt[(size_t)b * nseg + sidx];
+  int* code = reinterpret_cast<int*>(sh + L);  // enumeration rank of each strided entry (for tie-breaking) or taken / absent
+  __shared__ int s_off[1024];                  // exclusive prefix of leaf counts over the segments
+  for (int sidx = threadIdx.x; sidx < nseg; sidx += blockDim.x) s_off[sidx] = leaf_cnt[seg0 + sidx];
   __syncthreads();
   if (threadIdx.x == 0) {                      // counts -> exclusive prefix, in LDS
     int acc = 0;
@@ -769,25 +770,23 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
   }
   __syncthreads();
   for (int e = threadIdx.x; e < L; e += blockDim.x) {
-    const int seg = e / a.K, i = e % a.K;
-    const int cnt = a.leaf_cnt[(size_t)b * nseg + seg];
-    sc[e] = (i < cnt) ? a.leaf_score[((size_t)b * nseg + seg) * a.K + i] : -INFINITY;
+    const int seg = e / K, i = e % K;
+    const int cnt = leaf_cnt[seg0 + seg];
+    sc[e] = (i < cnt) ? leaf_score[(seg0 + seg) * K + i] : -INFINITY;
     code[e] = (i < cnt) ? s_off[seg] + i : 0x7fffffff;
   }
   __syncthreads();
-  if (s_off[nseg] < a.K) { if (threadIdx.x == 0) a.summary[4] = 1; return; }   // the reference asserts len >= k
-  __shared__ int s_win[NUC_MAX_KEEP];          // strided entry of the r-th best leaf
-  __shared__ float s_wsc[NUC_MAX_KEEP];
-  // Order: higher score first, equal scores by enumeration code (codes are unique).  Two levels, one barrier: every wave
-  // takes the K best of ITS quarter of the entries in K rounds of wave-wide arg-max (no workgroup barrier inside the
-  // rounds), then the <= 4K survivors are ranked against each other by counting — the K best overall are among them.
+  if (s_off[nseg] < K) return false;
+  // Two levels, one barrier: every wave takes the K best of ITS quarter of the entries in K rounds of wave-wide arg-max (no
+  // workgroup barrier inside the rounds), then the <= 4K survivors are ranked against each other by counting — the K best
+  // overall are among them.
   __shared__ float s_csc[4 * NUC_MAX_KEEP];
   __shared__ int s_ccode[4 * NUC_MAX_KEEP];
   __shared__ int s_ce[4 * NUC_MAX_KEEP];
   {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int per_wave = (L + 3) / 4, lo = wave * per_wave, hi = min(L, lo + per_wave);
-    for (int r = 0; r < a.K; ++r) {
+    for (int r = 0; r < K; ++r) {
       float best = -INFINITY;
       int bc = 0x7fffffff, be = -1;
       for (int e = lo + lane; e < hi; e += 64) {
@@ -803,7 +802,7 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
         if (oe >= 0 && (be < 0 || ov > best || (ov == best && oc < bc))) { best = ov; bc = oc; be = oe; }
       }
       if (lane == 0) {
-        s_csc[wave * a.K + r] = best; s_ccode[wave * a.K + r] = bc; s_ce[wave * a.K + r] = be;
+        s_csc[wave * K + r] = best; s_ccode[wave * K + r] = bc; s_ce[wave * K + r] = be;
         if (be >= 0) code[be] = 0x7fffffff;      // taken (the score stays: it is read again below)
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -812,20 +811,35 @@ __global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < 4 * a.K; t += blockDim.x) {
+  for (int t = threadIdx.x; t < 4 * K; t += blockDim.x) {
     const int e = s_ce[t];
     if (e < 0) continue;
     const float v = s_csc[t];
     const int cd = s_ccode[t];
     int rank = 0;
-    for (int u = 0; u < 4 * a.K; ++u) {
+    for (int u = 0; u < 4 * K; ++u) {
       if (s_ce[u] < 0) continue;
       const float ov = s_csc[u];
       rank += (ov > v || (ov == v && s_ccode[u] < cd)) ? 1 : 0;
     }
-    if (rank < a.K) { s_win[rank] = e; s_wsc[rank] = v; }
+    if (rank < K) { s_win[rank] = e; s_wsc[rank] = v; }
   }
   __syncthreads();
+  return true;
+}
+
+template <typename TokT>
+__global__ __launch_bounds__(256) void k_beam_select(BeamSelectArgs<TokT> a) {
+  extern __shared__ float sh[];                // scores [L] then codes [L] (as int)
+  const int b = blockIdx.x;
+  const int dl1 = a.dl + 1;
+  const int nseg = a.beam * dl1;
+  __shared__ int s_win[NUC_MAX_KEEP];          // strided entry of the r-th best leaf
+  __shared__ float s_wsc[NUC_MAX_KEEP];
+  if (!select_best_leaves(a.leaf_score, a.leaf_cnt, (size_t)b * nseg, nseg, a.K, sh, s_win, s_wsc)) {   // the reference asserts len >= k
+    if (threadIdx.x == 0) a.summary[4] = 1;
+    return;
+  }
   // the K new rows, all at once: root tokens, the kept draft tokens, the leaf token
   for (int e = threadIdx.x; e < a.K * a.width; e += blockDim.x) {
     const int r = e / a.width, col = e - r * a.width;
@@ -1088,6 +1102,12 @@ struct BeamLeaves2Args {
   int n_cand, N, dl, K, bos, pad, smart;
   int* best_n; int* best_slot; int64_t* chosen;      // [max_cand], [max_cand], [max_cand, dl]
   float* leaf_score; int* leaf_tok; int* leaf_cnt;
+  // source pool (ttx_beam_speculative_generate_pool); all null / 0 on the per-batch path
+  const uint8_t* live;     // [max_cand] 0: no candidate in this slot (its segments get no leaves)
+  int pool_K;              // candidates per source slot: in smart mode the -1-padded table is as wide as the SOURCE's longest
+                           // group (what the source would see alone in a batch), not the whole launch's
+  uint8_t* sens;           // [max_cand] smart mode: 1 if some wider table (up to N entries) would pick another draft — then the
+                           // candidate's outcome depends on the other sources of its given batch (scheduling.replay_beam_batch)
 };
 
 // One workgroup per candidate.  (1) Accepted length of each of its drafts = leading hits of k_bs_hits (finished candidates
@@ -1107,6 +1127,10 @@ __global__ __launch_bounds__(BS_LEAVES_THREADS) void k_bs_leaves(BeamLeaves2Args
   const int c = blockIdx.x;
   if (c >= a.n_cand) return;
   const int dl1 = a.dl + 1;
+  if (a.live && !a.live[c]) {
+    for (int p = threadIdx.x; p < dl1; p += blockDim.x) a.leaf_cnt[(size_t)c * dl1 + p] = 0;
+    return;
+  }
   const int pc = a.per_cand[c];
   const bool fin = a.finished[c] != 0;
   for (int i = threadIdx.x; i < pc; i += blockDim.x) {
@@ -1119,12 +1143,28 @@ __global__ __launch_bounds__(BS_LEAVES_THREADS) void k_bs_leaves(BeamLeaves2Args
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int W = a.smart ? a.cnt->max_group : a.N;
+    int W = a.N;
+    if (a.smart && a.pool_K > 0) {
+      W = 1;
+      const int c0 = (c / a.pool_K) * a.pool_K;
+      for (int k = 0; k < a.pool_K; ++k) W = max(W, a.per_cand[c0 + k]);
+    } else if (a.smart) {
+      W = a.cnt->max_group;
+    }
     for (int i = 0; i < W; ++i) s_v[i] = (i < pc) ? (long long)s_nok[i] : -1ll;
     const int best = ttxsel::topk1_index(s_v, s_ix, W);
     s_best = best;
     a.best_n[c] = s_nok[best];
     a.best_slot[c] = best;
+    if (a.sens) {
+      uint8_t sv = 0;
+      if (a.smart && !fin)
+        for (int W2 = W + 1; W2 <= a.N && !sv; ++W2) {
+          for (int i = 0; i < W2; ++i) s_v[i] = (i < pc) ? (long long)s_nok[i] : -1ll;
+          if (ttxsel::topk1_index(s_v, s_ix, W2) != best) sv = 1;
+        }
+      a.sens[c] = sv;
+    }
   }
   __syncthreads();
   const int best = s_best;
@@ -1249,6 +1289,315 @@ __global__ __launch_bounds__(256) void k_beam_step(BeamStepArgs a) {
       tot[sel] = -INFINITY;
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Beam-speculative SOURCE POOL (ttx_beam_speculative_generate_pool): continuous batching over the sources of many given
+// batches.  In the reference's loop the sources of a batch interact only through batch-wide scalars — the shared tensor width,
+// the draft length min(max_len - longest row - 1, draft_len) (:476/:671), the stop rule (every row holds EOS, :586) and, in
+// smart mode, the width of the -1-padded table the best draft is picked from (the batch's longest group, :779-784 -> :225) —
+// while a source's candidates, leaves, scores and selection depend on that source alone (and a source all of whose n_best rows
+// hold EOS is a fixed point of the iteration: one PAD leaf per row with log-prob + 0).  So every source is decoded under the
+// rule it would see ALONE in a batch, in a pool of C source slots (K = n_best candidate slots each) that is refilled from a
+// length-sorted work list as sources finish, one verify step per iteration over all live candidates (M ~ 10^4 step rows instead
+// of ~1.5 k), and per source and iteration the longest new row and the table-width data are recorded; the host then replays
+// the reference's batch loop over the batches AS GIVEN from those traces (scheduling.replay_beam_batch): output width, model
+// calls and counters come out exactly, and the rare batch whose scalars WOULD have coupled its sources (a row within
+// draft_len + 1 of max_len; a table-width-sensitive draft choice) is decoded again as given.
+//   iteration = k_bsp_prep -> k_tree_cache -> k_bs_list -> verify step -> k_bs_hits -> k_bs_leaves (pool arguments) ->
+//               k_bsp_select -> k_bsp_publish            (admission between iterations: k_bsp_admit -> k_bsp_fill)
+enum BeamPoolStatus { BP_RUNNING = 0, BP_DONE = 1, BP_ERR_LEAVES = 2, BP_IRREGULAR = 3, BP_MAX_STEPS = 4, BP_RUNAWAY = 5 };
+
+struct BeamPoolHost { int steps_done; int n_live; int n_running; int error; };     // pinned, device-mapped: written by k_bsp_publish
+
+// Caller-side arrays of one pool call (device pointers; constant for the call), in work-list order.
+struct BeamPoolIo {
+  int64_t* out;              // [R_total][K][max_len]: the hypotheses of every finished source, best first, PAD beyond
+  short* trace_len;          // [R_total][T_cap]: longest hypothesis (tokens) of the source after each of its iterations
+  unsigned char* trace_grp;  // [R_total][T_cap]: smart mode: bits 0-6 the source's longest draft group, bit 7 choice-sensitive
+  int* summary;              // [R_total][8]: iterations, BeamPoolStatus, input lines, running rows, accepted sum, accepted count,
+                             //               longest hypothesis at the end, decoded candidates summed over the iterations
+  const int* len_all;        // [R_total] source length (position after the last non-PAD token)
+  const int* given_all;      // [R_total] padded width of the batch the source was given in (smart mode: library size)
+  int T_cap;
+  int pad_;
+};
+
+struct BeamPoolArgs {
+  // slots
+  int C, K, N, D0, Ls_cap, max_len, ld;          // ld: row stride of the candidate rows (max_len + D0 + 2)
+  int smart, lib_ld, pad, bos, eos, repl, max_steps;
+  int* row_of; int* iter; int* given_ls; int* src_acc;      // [C], [C], [C], [C][8]
+  const int* tok;                                // [C][Ls_cap] source tokens per slot (PAD beyond the source)
+  const int* drafts_all;                         // all drafts: [C][N][D0]
+  // candidates ([C*K])
+  int64_t* cand_next; int* len_next; uint8_t* fin_next; float* logp_next; int* parent; int* parent_draft;
+  int* gen; int* front; int* len; uint8_t* active; uint8_t* finished; uint8_t* live; float* logp; int* per_cand; int* drafts32;
+  const uint8_t* sens; const int* chosen_slot; const int64_t* chosen;
+  const float* leaf_score; const int* leaf_tok; const int* leaf_cnt;
+  BeamCounters* cnt; const BeamPoolIo* io; BeamPoolHost* host; int* dev_summary;   // dev_summary [4]: live, running, error, -
+};
+
+__global__ void k_bsp_init(BeamPoolArgs a, int* src_of, int* cand_src_len) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  const int MC = a.C * a.K;
+  for (int i = tid; i < a.C; i += nth) { a.row_of[i] = -1; a.iter[i] = 0; a.given_ls[i] = 0; }
+  for (int i = tid; i < a.C * 8; i += nth) a.src_acc[i] = 0;
+  for (int i = tid; i < MC; i += nth) {
+    a.len_next[i] = 1; a.fin_next[i] = 1; a.logp_next[i] = 0.f; a.parent[i] = -1; a.parent_draft[i] = 0;
+    a.active[i] = 0; a.finished[i] = 1; a.live[i] = 0; a.per_cand[i] = 0;
+    src_of[i] = i / a.K; cand_src_len[i] = 1;
+  }
+  if (tid == 0) {
+    a.cnt->model_calls = 0; a.cnt->input_lines = 0; a.cnt->running_rows = 0; a.cnt->verified_positions = 0; a.cnt->executed_positions = 0;
+    a.cnt->kv_prefix_positions = 0; a.cnt->running_cands = 0; a.cnt->max_group = 0; a.cnt->pad_ = 0;
+    a.dev_summary[0] = 0; a.dev_summary[1] = 0; a.dev_summary[2] = 0; a.dev_summary[3] = 0;
+    a.host->steps_done = 0; a.host->n_live = 0; a.host->n_running = 0; a.host->error = 0;
+    __threadfence_system();
+  }
+}
+
+// One block.  The R new sources (rows first_row .. first_row + R - 1 of the work list) take the lowest free slots in order.
+__global__ __launch_bounds__(256) void k_bsp_admit(BeamPoolArgs a, int* new_slot, int* cand_src_len, int R, int first_row) {
+  if (threadIdx.x != 0) return;
+  int got = 0;
+  for (int s = 0; s < a.C && got < R; ++s) {
+    if (a.row_of[s] >= 0) continue;
+    const int row = first_row + got;
+    new_slot[got] = s;
+    a.row_of[s] = row;
+    a.iter[s] = 0;
+    a.given_ls[s] = a.io->given_all[row];
+    for (int q = 0; q < 8; ++q) a.src_acc[s * 8 + q] = 0;
+    for (int k = 0; k < a.K; ++k) cand_src_len[s * a.K + k] = a.io->len_all[row];
+    ++got;
+  }
+  // the host only admits as many sources as it knows to be free, so got == R
+  if (got != R) { a.dev_summary[2] = 1; a.host->error = 1; __threadfence_system(); }
+}
+
+struct BeamPoolFillArgs {
+  const int* new_slot; int R; int first_row;
+  int C, K, N, D0, ld, Ls_cap, Ls_new, max_len, pad, bos;
+  int64_t* cand_next; int* len_next; uint8_t* fin_next; float* logp_next; int* parent; int* parent_draft;
+  int* tok; const int* tok_new;                                       // [C][Ls_cap] <- [R][Ls_new]
+  uint8_t* src_valid; const uint8_t* valid_new;
+  int* drafts_all; const int* drafts_new;                             // all drafts: [C][N*D0] <- [R][N*D0] (null in smart mode)
+  float* memkv; const float* memkv_new; int kv_row;                   // floats per source position (Ld * 2 * d)
+  const BeamPoolIo* io;
+};
+
+// grid (R, 1 + Ls_new): block (i, 0) initialises source i's slot (candidate rows, tokens, drafts) and its caller-side rows,
+// block (i, 1 + key) copies the cross K/V of one source position.
+__global__ __launch_bounds__(256) void k_bsp_fill(BeamPoolFillArgs a) {
+  const int i = blockIdx.x;
+  const int s = a.new_slot[i];
+  const int t = threadIdx.x;
+  if (blockIdx.y == 0) {
+    for (int e = t; e < a.K * a.ld; e += blockDim.x) a.cand_next[(size_t)s * a.K * a.ld + e] = (e == 0) ? a.bos : a.pad;
+    for (int k = t; k < a.K; k += blockDim.x) {
+      const int c = s * a.K + k;
+      a.len_next[c] = 1; a.fin_next[c] = 0; a.logp_next[c] = 0.f; a.parent[c] = -1; a.parent_draft[c] = 0;
+    }
+    for (int c = t; c < a.Ls_cap; c += blockDim.x) {
+      a.tok[(size_t)s * a.Ls_cap + c] = (c < a.Ls_new) ? a.tok_new[(size_t)i * a.Ls_new + c] : a.pad;
+      a.src_valid[(size_t)s * a.Ls_cap + c] = (c < a.Ls_new) ? a.valid_new[(size_t)i * a.Ls_new + c] : (uint8_t)0;
+    }
+    if (a.drafts_new)
+      for (int c = t; c < a.N * a.D0; c += blockDim.x) a.drafts_all[(size_t)s * a.N * a.D0 + c] = a.drafts_new[(size_t)i * a.N * a.D0 + c];
+    const size_t row = (size_t)(a.first_row + i);
+    const BeamPoolIo io = *a.io;
+    for (int c = t; c < a.K * a.max_len; c += blockDim.x) io.out[row * a.K * a.max_len + c] = a.pad;
+    for (int c = t; c < io.T_cap; c += blockDim.x) { io.trace_len[row * io.T_cap + c] = -1; io.trace_grp[row * io.T_cap + c] = 0; }
+    for (int c = t; c < 8; c += blockDim.x) io.summary[row * 8 + c] = 0;
+  } else {
+    const int key = blockIdx.y - 1;
+    const float4* src = reinterpret_cast<const float4*>(a.memkv_new + ((size_t)i * a.Ls_new + key) * a.kv_row);
+    float4* dst = reinterpret_cast<float4*>(a.memkv + ((size_t)s * a.Ls_cap + key) * a.kv_row);
+    for (int c = t; c < a.kv_row / 4; c += blockDim.x) dst[c] = src[c];
+  }
+}
+
+// One workgroup per candidate slot c = s * K + k: k_bs_prep for the pool.  A slot without a source, or a candidate index the
+// source does not have yet (a fresh source has ONE <BOS> candidate, :447-459), is dead: not decoded, no leaves.  Smart mode
+// reads the library straight from the source tokens: make_drafts(src, draft_len + 1, Ls - 5, ...) (:603-615) returns ALL
+// Ls - 5 stride-1 windows of the row padded to the GIVEN batch's width Ls, in order (it asks for as many drafts as there are
+// windows), with EOS / PAD replaced by the replace token — window i is tokens i .. i + lib_ld - 1.
+__global__ __launch_bounds__(256) void k_bsp_prep(BeamPoolArgs a) {
+  __shared__ int s_scan[256];
+  __shared__ int s_match[BS_MAX_SLOTS];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int s = c / a.K, k = c - s * a.K;
+  const int row_id = a.row_of[s];
+  const int beam = (row_id >= 0) ? (a.iter[s] == 0 ? 1 : a.K) : 0;
+  if (k >= beam) {
+    if (t == 0) { a.active[c] = 0; a.finished[c] = 1; a.live[c] = 0; a.per_cand[c] = 0; a.len[c] = 1; a.front[c] = 0; }
+    return;
+  }
+  const int64_t* row = a.cand_next + (size_t)c * a.ld;
+  for (int col = t; col < a.ld; col += 256) a.gen[(size_t)c * a.ld + col] = (int)row[col];
+  const int lc = a.len_next[c];
+  const int fin = a.fin_next[c];
+  if (t == 0) {
+    a.len[c] = lc; a.front[c] = lc - 1; a.finished[c] = (uint8_t)fin; a.active[c] = fin ? 0 : 1; a.live[c] = 1; a.logp[c] = a.logp_next[c];
+  }
+  const int dl = a.D0;
+  int* dst = a.drafts32 + (size_t)c * a.N * dl;
+  if (!a.smart) {
+    const int* src = a.drafts_all + (size_t)s * a.N * a.D0;
+    for (int e = t; e < a.N * dl; e += 256) dst[e] = src[e];
+    if (t == 0) a.per_cand[c] = a.N;
+    return;
+  }
+  const int last = (int)row[lc - 1];
+  const int* tk = a.tok + (size_t)s * a.Ls_cap;
+  const int n_lib = a.given_ls[s] - 5;
+  auto lib_tok = [&](int pos) {                      // token `pos` of the padded, service-token-free source row
+    const int v = (pos < a.Ls_cap) ? tk[pos] : a.pad;
+    return (v == a.eos || v == a.pad) ? a.repl : v;
+  };
+  int running = 0;
+  for (int base = 0; base < n_lib && running < a.N; base += 256) {
+    const int i = base + t;
+    const int flag = (i < n_lib && lib_tok(i) == last) ? 1 : 0;
+    const int incl = block_scan_incl256(flag, s_scan);
+    const int pos = running + incl - 1;
+    if (flag && pos < a.N) s_match[pos] = i;
+    running += s_scan[255];
+    __syncthreads();
+  }
+  int count = running < a.N ? running : a.N;
+  if (count == 0) {                                   // "each line needs at least one draft" (:417)
+    if (t == 0) s_match[0] = 0;
+    count = 1;
+  }
+  __syncthreads();
+  for (int e = t; e < a.N * dl; e += 256) {
+    const int n = e / dl, j = e % dl;
+    dst[e] = lib_tok(s_match[n < count ? n : 0] + 1 + j);
+  }
+  if (t == 0) a.per_cand[c] = count;
+}
+
+// One workgroup per source slot: k_beam_select for the pool (the n_best best leaves of the source's candidates and the new
+// rows), then the source's own bookkeeping: trace entry, sums, and — when every new row holds EOS, or the source can no longer
+// be decoded under the pool's rule — its hypotheses go to the caller's array and the slot is freed.
+__global__ __launch_bounds__(256) void k_bsp_select(BeamPoolArgs a) {
+  extern __shared__ float sh[];
+  __shared__ int s_win[NUC_MAX_KEEP];
+  __shared__ float s_wsc[NUC_MAX_KEEP];
+  __shared__ int s_eos, s_maxreal, s_accsum, s_acccnt, s_running_next;
+  const int s = blockIdx.x, t = threadIdx.x;
+  const int row_id = a.row_of[s];
+  if (row_id < 0) return;
+  const int it0 = a.iter[s];
+  const int beam = it0 == 0 ? 1 : a.K;
+  const int dl = a.D0, dl1 = dl + 1, K = a.K;
+  const int c0 = s * K;
+  const size_t seg0 = (size_t)c0 * dl1;
+  if (t == 0) { s_eos = 0; s_maxreal = 0; s_accsum = 0; s_acccnt = 0; s_running_next = 0; }
+  const bool enough = select_best_leaves(a.leaf_score, a.leaf_cnt, seg0, beam * dl1, K, sh, s_win, s_wsc);   // ends with a barrier
+  const BeamPoolIo io = *a.io;
+  int status = BP_RUNNING;
+  if (!enough) {
+    status = BP_ERR_LEAVES;
+  } else {
+    // the K new rows: root tokens, the kept draft tokens, the leaf token (the rows of c0 .. c0 + K - 1 are rewritten in place
+    // of the NEXT buffer; the roots are read from `gen`, which k_bsp_prep copied)
+    for (int e = t; e < K * a.ld; e += blockDim.x) {
+      const int r = e / a.ld, col = e - r * a.ld;
+      const int sel = s_win[r];
+      const int seg = sel / K, i = sel % K;
+      const int cl = seg / dl1, p = seg % dl1;
+      const int c = c0 + cl;
+      const int tok = a.leaf_tok[(seg0 + seg) * K + i];
+      const int lc = a.len[c];
+      int64_t v = (int64_t)a.gen[(size_t)c * a.ld + col];
+      const int j = col - lc;
+      if (j >= 0 && j <= dl) v = (j < p) ? a.chosen[(size_t)c * dl + j] : (j == p ? (int64_t)tok : (int64_t)a.pad);
+      a.cand_next[(size_t)(c0 + r) * a.ld + col] = v;
+    }
+    // per new row: score, parent, length, EOS flag (read every root's state BEFORE any of the next-iteration arrays of this
+    // source is overwritten: they are distinct arrays, `len`/`finished` vs `len_next`/`fin_next`)
+    for (int r = t; r < K; r += blockDim.x) {
+      const int sel = s_win[r];
+      const int seg = sel / K, i = sel % K;
+      const int cl = seg / dl1, p = seg % dl1;
+      const int c = c0 + cl, out = c0 + r;
+      const int tok = a.leaf_tok[(seg0 + seg) * K + i];
+      const int lc = a.len[c];
+      const int fin_root = a.finished[c];
+      const bool has_eos = fin_root || tok == a.eos;       // accepted draft tokens are never EOS (drafting.py:65)
+      const int real = (tok == a.pad) ? lc + p : lc + p + 1;
+      a.logp_next[out] = s_wsc[r];
+      a.parent[out] = c;
+      a.parent_draft[out] = a.chosen_slot[c];
+      a.len_next[out] = real;
+      a.fin_next[out] = has_eos ? 1 : 0;
+      if (has_eos) atomicAdd(&s_eos, 1); else atomicAdd(&s_running_next, 1);
+      atomicMax(&s_maxreal, real);
+      if (!fin_root) { atomicAdd(&s_accsum, p); atomicAdd(&s_acccnt, 1); }
+    }
+  }
+  __syncthreads();
+  // the source's iteration record
+  const int it = it0 + 1;
+  int lines = 0, running = 0, grp = 0, sens = 0, run_cands = 0;
+  if (t == 0) {
+    for (int k = 0; k < beam; ++k) {
+      const int pc = a.per_cand[c0 + k];
+      lines += pc;
+      if (!a.finished[c0 + k]) { running += pc; ++run_cands; }
+      grp = max(grp, pc);
+      if (a.sens) sens |= a.sens[c0 + k];
+    }
+    int* acc = a.src_acc + s * 8;
+    acc[0] += lines; acc[1] += running; acc[2] += s_accsum; acc[3] += s_acccnt; acc[4] += run_cands;
+    if (it - 1 < io.T_cap) {
+      io.trace_len[(size_t)row_id * io.T_cap + it - 1] = (short)s_maxreal;
+      io.trace_grp[(size_t)row_id * io.T_cap + it - 1] = (unsigned char)((grp & 0x7f) | (sens ? 0x80 : 0));
+    }
+    if (status == BP_RUNNING) {
+      if (s_eos == K) status = BP_DONE;                                              // :586 for a batch of this source alone
+      else if (s_maxreal > a.max_len - 1 - a.D0) status = BP_IRREGULAR;              // the next draft would be shorter (:476)
+      else if (a.max_steps > 0 && it >= a.max_steps) status = BP_MAX_STEPS;
+      else if (it >= io.T_cap) status = BP_RUNAWAY;
+    }
+    a.iter[s] = it;
+    s_eos = status;                                    // broadcast
+  }
+  __syncthreads();
+  status = s_eos;
+  if (status == BP_RUNNING) {
+    if (t == 0) { atomicAdd(&a.dev_summary[0], 1); atomicAdd(&a.dev_summary[1], s_running_next); }
+    return;
+  }
+  // retire: hypotheses (a finished source only) and the summary go to the caller's arrays, the slot is free again
+  if (status == BP_DONE)
+    for (int e = t; e < K * a.max_len; e += blockDim.x) {
+      const int r = e / a.max_len, col = e - r * a.max_len;
+      io.out[((size_t)row_id * K + r) * a.max_len + col] = a.cand_next[(size_t)(c0 + r) * a.ld + col];
+    }
+  if (t == 0) {
+    const int* acc = a.src_acc + s * 8;
+    int* sm = io.summary + (size_t)row_id * 8;
+    sm[0] = it; sm[1] = status; sm[2] = acc[0]; sm[3] = acc[1]; sm[4] = acc[2]; sm[5] = acc[3]; sm[6] = s_maxreal; sm[7] = acc[4];
+    a.row_of[s] = -1;
+  }
+}
+
+// Last kernel of an iteration: live sources / running candidates of the NEXT iteration and the iteration count go to the
+// pinned words the host polls; the device-side tallies are reset for the next iteration.
+__global__ void k_bsp_publish(BeamPoolArgs a) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    a.host->n_live = a.dev_summary[0];
+    a.host->n_running = a.dev_summary[1];
+    if (a.dev_summary[2]) a.host->error = 1;
+    a.dev_summary[0] = 0; a.dev_summary[1] = 0;
+    __threadfence_system();
+    a.host->steps_done = (int)a.cnt->model_calls;
+    __threadfence_system();
   }
 }
 
