@@ -342,7 +342,10 @@ static int ensure_acts(ttx_session* s, hipStream_t st, size_t M, int qkv_layers)
 
 // ------------------------------------------------------------------------------------------------
 // Encoder: tokens int32 [B*Ls] + valid mask -> memory [B*Ls, d] (zeros at PAD rows).  modules.py:110-116
-static int run_encoder(ttx_session* s, hipStream_t st, const int* tok, const uint8_t* valid, int B, int Ls, float* memory) {
+// `qkv_buf`: where the encoder keeps its packed Q/K/V rows (default: the session's step buffer — callers whose NEXT step still
+// needs the previous step's Q/K/V rows, i.e. the beam source pool's deferred cache hand-over, pass a buffer of their own).
+static int run_encoder(ttx_session* s, hipStream_t st, const int* tok, const uint8_t* valid, int B, int Ls, float* memory,
+                       float* qkv_buf = nullptr) {
   const ttx_model* m = s->m;
   const ttx_config& c = m->cfg;
   const int d = c.embedding_dim, F = c.feedforward_dim, H = c.num_heads;
@@ -351,7 +354,7 @@ static int run_encoder(ttx_session* s, hipStream_t st, const int* tok, const uin
   TTX_TRY(ensure_acts(s, st, (size_t)M, 1));
   float* x = s->x.as<float>();
   float* x1 = s->x1.as<float>();
-  float* qkv = s->qkv.as<float>();
+  float* qkv = qkv_buf ? qkv_buf : s->qkv.as<float>();
   float* ao = s->ao.as<float>();
   float* hb = s->hbuf.as<float>();
   EmbedArgs e{};
@@ -1849,6 +1852,7 @@ static int bpool_start(BeamPoolJob& j, ttx_session* s, hipStream_t st, int C, in
   need(s->tok_src, (size_t)C * Ls_cap * 4); need(s->valid_new, (size_t)C * Ls_cap); need(s->src_valid, (size_t)C * Ls_cap);
   need(s->memory, (size_t)C * Ls_cap * d * 4); need(s->memkv_new, (size_t)C * Ls_cap * kv_row * 4); need(s->memkv, (size_t)C * Ls_cap * kv_row * 4);
   need(s->bp_tok, (size_t)C * Ls_cap * 4);
+  need(s->bp_enc_qkv, (size_t)C * Ls_cap * 3 * d * 4);      // admissions must not touch the step's Q/K/V rows (see run_encoder)
   need(s->drafts_new, (size_t)C * j.N * j.D0 * 4); need(s->bs_drafts_src, (size_t)C * j.N * j.D0 * 4);
   need(s->drafts, MC * j.N * j.D0 * 4);
   need(s->gen, MC * j.gen_ld * 4); need(s->front, MC * 4); need(s->act_idx, MC * 4);
@@ -1925,7 +1929,7 @@ static int bpool_admit(BeamPoolJob& j, const int64_t* d_src_rows, int ld_src, in
   hipLaunchKernelGGL(k_prepare_tokens_2d, dim3(cdiv(R * Ls_new, 256)), dim3(256), 0, st, d_src_rows, ld_src, s->tok_src.as<int>(),
                      s->valid_new.as<uint8_t>(), R, Ls_new, c.pad_token);
   HIP_TRY(hipGetLastError());
-  TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->valid_new.as<uint8_t>(), R, Ls_new, s->memory.as<float>()));
+  TTX_TRY(run_encoder(s, st, s->tok_src.as<int>(), s->valid_new.as<uint8_t>(), R, Ls_new, s->memory.as<float>(), s->bp_enc_qkv.as<float>()));
   const int gv = variant_for_rows(s, (long long)R * Ls_new, false);
   TTX_TRY(launch_gemm(s, st, s->memory.as<float>(), d, m->p(m->cross_kv_w), d, m->p(m->cross_kv_b), s->memkv_new.as<float>(),
                       kv_row, nullptr, R * Ls_new, kv_row, d, false, 0, 0, gv));

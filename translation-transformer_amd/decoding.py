@@ -39,6 +39,7 @@ class TranslationInferenceGreedySpeculative:
                             "src_tokens_padded": 0, "batches": 0}
         self.last_stats: N.GenStats | None = None
         self.last_failed_batches: list = []    # generate_many(on_error="skip"): batches on which the reference raises
+        self.last_batch_counters: list = []    # generate_many: what each batch added to the counter attributes (None: failed)
         self.record_step = 0           # parity tests: k > 0 keeps the logits of verify step k (see step_snapshot)
 
     def step_snapshot(self) -> dict:
@@ -100,6 +101,7 @@ class TranslationInferenceGreedySpeculative:
         if on_error not in ("raise", "skip"):
             raise ValueError("on_error must be 'raise' or 'skip'")
         self.last_failed_batches = []
+        self.last_batch_counters = [None] * len(batches)
         if not batches:
             return []
         if reorder:
@@ -136,6 +138,7 @@ class TranslationInferenceGreedySpeculative:
                 self.last_failed_batches.append(i)
                 continue
             self.model_calls_num += int(st.model_calls)
+            self.last_batch_counters[i] = {"model_calls_num": int(st.model_calls)}
             for k in ("accepted_tokens", "produced_tokens", "verified_positions", "kv_prefix_positions", "src_positions",
                       "encode_ms", "decode_ms"):
                 t[k] += getattr(st, k)
@@ -231,6 +234,7 @@ class TranslationInferenceGreedySpeculative:
                 break
             keep[r0:r0 + B] = torch.from_numpy(rep.finished)
             self.model_calls_num += rep.model_calls
+            self.last_batch_counters[bi] = {"model_calls_num": rep.model_calls}
             t["accepted_tokens"] += rep.accepted_tokens
             t["produced_tokens"] += rep.produced_tokens
             t["verified_positions"] += rep.verified_positions
@@ -358,6 +362,8 @@ class TranslationInferenceBeamSearchSpeculative:
         # Safety valve absent from the reference, whose loop never ends when a candidate keeps emitting PAD before any
         # EOS; None = reference behaviour.
         self.max_steps = max_steps
+        self.last_failed_batches: list = []    # generate_many(on_error="skip"): batches on which the reference raises / the guard trips
+        self.last_batch_counters: list = []    # generate_many: what each batch added to the counter attributes (None: failed)
         # work the device executed, for bench.py's roofline
         self.stats_total = {"verified_positions": 0, "executed_positions": 0, "kv_prefix_positions": 0, "running_candidates": 0,
                             "src_tokens_padded": 0, "src_positions": 0, "encode_ms": 0.0, "decode_ms": 0.0, "batches": 0}
@@ -371,6 +377,11 @@ class TranslationInferenceBeamSearchSpeculative:
     def _params(self) -> N.BeamParams:
         return N.BeamParams(self.max_len, self.n_best, self.draft_len, self.requested_drafts_num, int(bool(self.smart_drafts_mode)),
                             self.pad_token_idx, self.bos_token_idx, self.eos_token_idx, self.C_token_idx, int(self.max_steps or 0))
+
+    _COUNTERS = ("model_calls_num", "accepted_tokens_num", "produced_non_pad_tokens", "model_input_lines_num", "b_sz", "n_drafts")
+
+    def _counter_values(self) -> dict:
+        return {k: getattr(self, k) for k in self._COUNTERS}
 
     def _account(self, st: N.BeamStats, B: int) -> None:
         t = self.stats_total
@@ -418,6 +429,7 @@ class TranslationInferenceBeamSearchSpeculative:
         if on_error not in ("raise", "skip"):
             raise ValueError("on_error must be 'raise' or 'skip'")
         self.last_failed_batches = []
+        self.last_batch_counters = [None] * len(batches)
         if not batches:
             return []
         srcs = [b.to(m.device, torch.int64).contiguous() for b in batches]
@@ -460,7 +472,9 @@ class TranslationInferenceBeamSearchSpeculative:
                 self.last_failed_batches.append(index[i])
                 res.append(None)
                 continue
+            before = self._counter_values()
             self._account(st, s.shape[0])
+            self.last_batch_counters[index[i]] = {k: v - before[k] for k, v in self._counter_values().items()}
             res.append(o[:, :, :int(st.out_width)].contiguous())
         return res
 
@@ -525,6 +539,7 @@ class TranslationInferenceBeamSearchSpeculative:
                 again.append(bi)
             else:
                 res[bi] = out_rows[r0:r0 + B, :, :rep.out_width].contiguous()
+                before = self._counter_values()
                 self.model_calls_num += rep.model_calls
                 self.accepted_tokens_num += rep.accepted_tokens
                 self.produced_non_pad_tokens += rep.produced_non_pad_tokens
@@ -533,6 +548,7 @@ class TranslationInferenceBeamSearchSpeculative:
                     self.b_sz += rep.running_rows
                 else:
                     self.n_drafts += B * self.requested_drafts_num
+                self.last_batch_counters[bi] = {k: v - before[k] for k, v in self._counter_values().items()}
                 t["batches"] += 1
             r0 += B
         t["batches_decoded_as_given"] = t.get("batches_decoded_as_given", 0) + len(again)

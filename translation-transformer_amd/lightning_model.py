@@ -84,15 +84,17 @@ class _PredictAhead:
     walks a second iterator over the same (unshuffled: src/data_handling/seq2seq_wrappers.py:168-175) dataloader, `window`
     batches at a time; predict_step(i) checks that the batch it was handed holds exactly the tokens that were decoded for
     index i and returns that tensor — identical to generate(batch) (row-scheduled decoding replays the reference's loop per
-    given batch).  Any mismatch (a sampler that reorders, a dataloader that cannot be iterated twice) switches the
-    look-ahead off for the rest of the run and the batch is decoded on the spot.  A batch on which the reference raises is
-    left to generate() so that the error surfaces at the same predict_step as in the reference."""
+    given batch).  Any mismatch (a sampler that reorders) switches the look-ahead off for the rest of the run, the counters of
+    the batches that were decoded ahead but not served are taken back, and the batch is decoded on the spot.  A batch on which
+    the reference raises (or the max_steps guard trips) is left to generate() so that the error surfaces at the same
+    predict_step as in the reference — for every generator: the window is decoded with on_error="skip".  Only dataloaders that
+    can be iterated again are looked ahead on (a one-shot iterator would be consumed: the module then decodes per batch)."""
 
     def __init__(self, generator, loader, window: int, in_flight: int):
         self.generator, self.window, self.in_flight = generator, max(1, int(window)), max(1, int(in_flight))
         self.it = iter(loader)
         self.next_idx = 0            # index of the next batch the iterator yields
-        self.ready = {}              # batch index -> (src tokens on the device, prediction or None)
+        self.ready = {}              # batch index -> (src tokens on the device, prediction or None, its counter shares)
         self.enabled = True
         self.served = self.fallbacks = self.windows = 0
         self.decode_seconds = 0.0
@@ -112,13 +114,21 @@ class _PredictAhead:
         t0 = timer()
         if isinstance(g, D.TranslationInferenceGreedySpeculative):      # slot pools over all rows of the window
             preds = g.generate_many(pending, in_flight=self.in_flight, reorder=True, on_error="skip")
-        else:
-            preds = g.generate_many(pending, in_flight=self.in_flight)
+        else:                                                           # source pools over all sources of the window
+            preds = g.generate_many(pending, in_flight=self.in_flight, on_error="skip")
+        shares = list(getattr(g, "last_batch_counters", [])) or [None] * len(pending)
         self.decode_seconds += timer() - t0
         self.windows += 1
         for k, (src, pred) in enumerate(zip(pending, preds)):
-            self.ready[self.next_idx + k] = (src, pred)
+            self.ready[self.next_idx + k] = (src, pred, shares[k])
         self.next_idx += len(pending)
+
+    def _take_back(self, entries) -> None:
+        """The generator's counters without the batches that were decoded ahead but will be decoded again by generate()."""
+        for _, pred, share in entries:
+            if pred is not None and share:
+                for name, v in share.items():
+                    setattr(self.generator, name, getattr(self.generator, name) - v)
 
     def take(self, src: torch.Tensor, batch_idx: int):
         """The prediction prepared for batch `batch_idx`, or None (decode it now)."""
@@ -129,6 +139,7 @@ class _PredictAhead:
         hit = self.ready.pop(batch_idx, None)
         if hit is None or hit[0].shape != src.shape or not torch.equal(hit[0], src.to(hit[0].device)):
             self.enabled = False                       # not the batch that was decoded for this index: stop looking ahead
+            self._take_back(([hit] if hit is not None else []) + list(self.ready.values()))
             self.ready.clear()
             self.fallbacks += 1
             return None
@@ -179,12 +190,19 @@ class VanillaEncoderDecoderTransformerLightning(LightningModule):
 
     # -- native path ------------------------------------------------------------------------------
     def _weights_fingerprint(self) -> tuple:
-        return tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in self.model.parameters())
+        """Content checksum of the parameters (sum and absolute sum per tensor, float64, computed where the weights live): also
+        sees writes through ``p.data`` / optimiser swaps that bump no version counter."""
+        ps = list(self.model.parameters())
+        if not ps:
+            return ()
+        with torch.no_grad():
+            sums = torch.stack([torch.stack((p.detach().double().sum(), p.detach().double().abs().sum())) for p in ps]).cpu()
+        return tuple((tuple(p.shape), float(a), float(b)) for p, (a, b) in zip(ps, sums.tolist()))
 
     def build_native(self, device: int | str | torch.device | None = None, force: bool = False) -> None:
         """(Re)build the HIP model + generator from the current parameters (call after loading a checkpoint).  A second
-        call with untouched parameters (same storage, same version counters) keeps the HIP model and its warm sessions and
-        only makes a fresh generator (zeroed counters)."""
+        call with unchanged parameter VALUES (content checksum) keeps the HIP model and its warm sessions and only makes a
+        fresh generator (zeroed counters); ``force=True`` rebuilds regardless."""
         fp = self._weights_fingerprint()
         if not force and self.native is not None and fp == getattr(self, "_native_fp", None) and device is None:
             self.generator = self._create_generator()
@@ -251,7 +269,8 @@ class VanillaEncoderDecoderTransformerLightning(LightningModule):
         window = int(os.environ.get("TTX_PREDICT_WINDOW", str(self.predict_window)))
         if window > 0 and hasattr(self.generator, "generate_many"):
             loader = self._predict_loader()
-            if loader is not None:
+            # a second pass over the loader must not consume it: one-shot iterators (iter(x) is x) are decoded per batch
+            if loader is not None and iter(loader) is not loader:
                 self._ahead = _PredictAhead(self.generator, loader, window, int(os.environ.get("TTX_INFLIGHT", "8")))
         if self.report_prediction_time:
             self.prediction_start_time = timer()
