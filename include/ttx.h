@@ -205,33 +205,32 @@ int ttx_beam_speculative_generate_many(ttx_session** sessions, int n_sessions, i
                                        const int* B, const int* Ls, const ttx_beam_params* p, int64_t* const* d_out,
                                        ttx_beam_stats* stats, void* stream);
 
-/* The same generator with continuous batching over the SOURCES of many given batches (SURVEY.md §8(f) #1 for the beam path).
- * In the reference's loop the sources of a batch meet only in batch-wide scalars: the tensor width, the draft length
- * min(max_len - longest row - 1, draft_len) (:476 / :671), the stop rule "every row holds EOS" (:586 / :826) and, in smart
- * mode, the width of the -1-padded table the best draft is picked from (the batch's longest draft group, :779-784 -> :225).
- * A source all of whose n_best rows hold EOS is a fixed point of the iteration.  This entry point therefore decodes every
- * source under the rule it would see ALONE in a batch, in pools of `capacity` source slots per session that are refilled from
- * the work list as sources finish (one verify step per iteration over all live candidates of a pool), and returns per source
- *   d_out        int64 [R_total][n_best][max_len]  hypotheses best first, PAD beyond (written when the source finished)
+/* The same generator with continuous batching over many given batches (SURVEY.md §8(f) #1 for the beam path).  In the
+ * reference's loop the sources of a batch meet only in batch-wide scalars: the draft length min(max_len - longest row - 1,
+ * draft_len) (:476 / :671), the stop rule (every row holds EOS, :586 / :826, or no room left, :464 / :652), the tensor width
+ * and, in smart mode, the width of the -1-padded table the best draft is picked from (the batch's longest draft group,
+ * :779-784 -> :225); a source all of whose n_best rows hold EOS is a fixed point of the iteration.  A session here owns a pool
+ * of `capacity` source slots: given batches are admitted whole (their sources run in lock-step), ONE verify step per iteration
+ * serves every live candidate of every batch in the pool, the batch-wide scalars are kept per batch on the device exactly as
+ * the reference computes them, a source that finished frees its slots at once, and the pool is refilled from the work list.
+ * Per source it returns
+ *   d_out        int64 [R_total][n_best][max_len]  hypotheses best first, PAD beyond
  *   d_trace_len  int16 [R_total][trace_cap]        longest hypothesis after each of the source's iterations (-1 past the last)
- *   d_trace_grp  uint8 [R_total][trace_cap]        smart mode: bits 0-6 the source's longest draft group of that iteration,
- *                                                  bit 7 set when a wider table (up to n_drafts) would pick another draft
- *   d_summary    int32 [R_total][8]                iterations, status (1 finished, 2 fewer leaves than n_best: the reference
- *                                                  asserts, 3 a row came within draft_len + 1 of max_len: decode the batch as
- *                                                  given, 4 max_steps, 5 more than trace_cap iterations), input lines, running
- *                                                  rows, accepted-token sum, accepted count, longest hypothesis, decoded
- *                                                  candidates summed over the iterations
- * from which a caller replays the reference's loop over the batches AS GIVEN (translation-transformer_amd/scheduling.py
- * replay_beam_batch: result width, model calls, counters; batches whose scalars would have coupled their sources are decoded
- * again with ttx_beam_speculative_generate_many).  d_src int64 [R_total][Ls_all] all sources right-padded, in admission order;
- * h_len / h_given_ls (HOST, int32 [R_total]): a source's length (position after its last non-PAD token) and the padded width
- * of the batch it was given in (smart mode builds its window library over that width, :603-615).  `stats` receives the sums of
- * what the device executed (model_calls = iterations of all pools).  TTX_ERR_INVALID when max_len - 2 < draft_len (the very
- * first draft would be cut: decode as given). */
+ *   d_summary    int32 [R_total][8]                iterations of its batch when it retired, status (1 every row holds EOS,
+ *                                                  3 its batch ran out of room: rows as they stood, 2 fewer leaves than
+ *                                                  n_best: the reference asserts for the batch, 4 max_steps), input lines,
+ *                                                  running rows, accepted-token sum, accepted count, longest hypothesis,
+ *                                                  decoded candidates summed over the iterations
+ * from which translation-transformer_amd/scheduling.py:replay_beam_batch derives each given batch's result width, model calls
+ * and counters.  d_src int64 [R_total][Ls_all]: all sources right-padded, batch after batch in admission order; HOST arrays:
+ * h_len int32 [R_total] a source's length (position after its last non-PAD token), h_batch_of int32 [R_total] its batch
+ * (0, 0, .., 1, 1, ...: non-decreasing, every batch non-empty and at most `capacity` sources), h_given_ls int32 [n_batches] the
+ * padded width each batch was given in (smart mode builds its window library over that width, :603-615).  `stats` receives the
+ * sums of what the device executed (model_calls = iterations of all pools). */
 int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_sessions, const int64_t* d_src, int R_total, int Ls_all,
-                                       const int32_t* h_len, const int32_t* h_given_ls, int capacity, const ttx_beam_params* p,
-                                       int64_t* d_out, int16_t* d_trace_len, uint8_t* d_trace_grp, int32_t* d_summary, int trace_cap,
-                                       ttx_beam_stats* stats, void* stream);
+                                       const int32_t* h_len, const int32_t* h_batch_of, int n_batches, const int32_t* h_given_ls,
+                                       int capacity, const ttx_beam_params* p, int64_t* d_out, int16_t* d_trace_len,
+                                       int32_t* d_summary, int trace_cap, ttx_beam_stats* stats, void* stream);
 
 /* TranslationInferenceBeamSearch.generate (src/decoding/standard_decoding.py:89-174) — the whole loop on the device with a
  * per-hypothesis KV cache: the <BOS> step (:102), then up to max_len - 2 iterations of {decoder on the unfinished hypotheses,

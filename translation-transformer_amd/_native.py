@@ -114,7 +114,8 @@ SYMBOLS = {
                                                     C.POINTER(C.c_int), C.POINTER(BeamParams), C.POINTER(_VP),
                                                     C.POINTER(BeamStats), _VP]),
     "ttx_beam_speculative_generate_pool": (C.c_int, [C.POINTER(_VP), _I, _VP, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I,
-                                                    C.POINTER(BeamParams), _VP, _VP, _VP, _VP, _I, C.POINTER(BeamStats), _VP]),
+                                                    C.POINTER(C.c_int32), _I, C.POINTER(BeamParams), _VP, _VP, _VP, _I,
+                                                    C.POINTER(BeamStats), _VP]),
     "ttx_beam_generate": (C.c_int, [_VP, _VP, _I, _I, C.POINTER(BeamSearchParams), _VP, C.POINTER(BeamSearchStats), _VP]),
     "ttx_nucleus_mask": (C.c_int, [_VP, _VP, _I, _I, C.c_float, _I, C.c_float, _VP, _VP]),
     "ttx_accepted_lengths": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _I, _VP, _VP]),

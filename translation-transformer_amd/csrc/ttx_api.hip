@@ -1812,9 +1812,10 @@ extern "C" int ttx_beam_speculative_generate(ttx_session* s, const int64_t* d_sr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Beam-speculative source pool (kernels and the argument for exactness: "Beam-speculative SOURCE POOL" in
-// ttx_loop_kernels.hip.h).  Host side: one job per session, each a pool of C source slots fed from the caller's work list;
-// an iteration is one fixed launch sequence (captured once per cache parity and GEMM variant) over every live candidate.
+// Beam-speculative batch pool (kernels and the argument for exactness: "Beam-speculative BATCH POOL" in
+// ttx_loop_kernels.hip.h).  Host side: one job per session, each a pool of C source slots fed with whole batches from the
+// caller's work list; an iteration is one fixed launch sequence (captured once per cache parity and GEMM variant) over every
+// live candidate of every batch in the pool.
 struct BeamPoolJob {
   ttx_session* s = nullptr;
   hipStream_t st = nullptr;
@@ -1832,7 +1833,7 @@ struct BeamPoolJob {
 };
 
 static int bpool_start(BeamPoolJob& j, ttx_session* s, hipStream_t st, int C, int Ls_cap, const ttx_beam_params* p, const BeamPoolIo& io_host,
-                       const int32_t* h_len, const int32_t* h_given, int R_total) {
+                       const int32_t* h_len, const int32_t* h_batch_of, const int32_t* h_given, int R_total, int n_batches) {
   const ttx_model* m = s->m;
   const ttx_config& c = m->cfg;
   const int d = c.embedding_dim, Ld = c.num_decoder_layers, V = c.vocab_size;
@@ -1863,14 +1864,16 @@ static int bpool_start(BeamPoolJob& j, ttx_session* s, hipStream_t st, int C, in
   need(s->bs_len, MC * 4); need(s->bs_fin, MC); need(s->bs_active, MC); need(s->bs_logp, MC * 4); need(s->bs_per_cand, MC * 4);
   need(s->bs_best_n, MC * 4); need(s->bs_best_slot, MC * 4); need(s->bs_chosen, MC * j.D0 * 8);
   need(s->bs_hit, MC * (size_t)j.N * j.D0); need(s->bs_mark, MC);            // bs_mark: the live flags of the pool
-  need(s->bs_parent, MC * 4); need(s->bs_parent_draft, MC * 4); need(s->bp_sens, MC);
+  need(s->bs_parent, MC * 4); need(s->bs_parent_draft, MC * 4); need(s->bp_cand, MC * 8);      // cand_dl, cand_batch
   need(s->bs_cnt, sizeof(BeamCounters));
   const size_t dl1 = (size_t)j.D0 + 1;
   need(s->leaf_score, MC * dl1 * j.K * 4); need(s->leaf_tok, MC * dl1 * j.K * 4); need(s->leaf_cnt, MC * dl1 * 4);
   need(s->beam_summary, 8 * 4); need(s->bp_grp, 4 * 4);
-  need(s->bp_row_of, (size_t)C * 4); need(s->bp_iter, (size_t)C * 4); need(s->bp_given_ls, (size_t)C * 4); need(s->bp_src_acc, (size_t)C * 32);
+  need(s->bp_row_of, (size_t)C * 4 * 3);                        // row_of, slot_batch, src_state
+  need(s->bp_batch, (size_t)C * 4 * 10);                        // ten per-batch-slot arrays
+  need(s->bp_src_acc, (size_t)C * 32);
   need(s->bp_new_slot, (size_t)C * 4);
-  need(s->bp_io, sizeof(BeamPoolIo) + (size_t)R_total * 8);
+  need(s->bp_io, sizeof(BeamPoolIo) + ((size_t)R_total * 2 + n_batches) * 4);
   const size_t Macts = std::max(Mmax, (size_t)C * Ls_cap);
   if (rc == TTX_OK) rc = ensure_acts(s, st, Macts, 1);
   need(s->qkv, std::max((size_t)Ld * Mmax, (size_t)C * Ls_cap) * 3 * d * 4);
@@ -1888,27 +1891,36 @@ static int bpool_start(BeamPoolJob& j, ttx_session* s, hipStream_t st, int C, in
   HIP_TRY(hipHostGetDevicePointer((void**)&dev_host, (void*)s->bp_host, 0));
   s->ev_used = 0;
   HIP_TRY(hipEventRecord(s->ev_a, st));
-  // the caller-side pointer block and the per-source lengths live in one device allocation: [BeamPoolIo][len_all][given_all]
+  // the caller-side pointer block and the work list's lengths live in one device allocation:
+  // [BeamPoolIo][len_all: R_total][batch_all: R_total][given_all: n_batches]
   char* io_dev = s->bp_io.as<char>();
   int* len_dev = reinterpret_cast<int*>(io_dev + sizeof(BeamPoolIo));
-  int* given_dev = len_dev + R_total;
+  int* batch_dev = len_dev + R_total;
+  int* given_dev = batch_dev + R_total;
   j.io = io_host;
-  j.io.len_all = len_dev; j.io.given_all = given_dev;
+  j.io.len_all = len_dev; j.io.batch_all = batch_dev; j.io.given_all = given_dev;
   HIP_TRY(hipMemcpyAsync(io_dev, &j.io, sizeof(BeamPoolIo), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(len_dev, h_len, (size_t)R_total * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(given_dev, h_given, (size_t)R_total * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(batch_dev, h_batch_of, (size_t)R_total * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(given_dev, h_given, (size_t)n_batches * 4, hipMemcpyHostToDevice, st));
   BeamPoolArgs& a = j.a;
   a.C = C; a.K = j.K; a.N = j.N; a.D0 = j.D0; a.Ls_cap = Ls_cap; a.max_len = p->max_len; a.ld = j.gen_ld;
   a.smart = j.smart ? 1 : 0; a.lib_ld = j.lib_ld; a.pad = p->pad_token; a.bos = p->bos_token; a.eos = p->eos_token; a.repl = p->replace_token;
   a.max_steps = p->max_steps;
-  a.row_of = s->bp_row_of.as<int>(); a.iter = s->bp_iter.as<int>(); a.given_ls = s->bp_given_ls.as<int>(); a.src_acc = s->bp_src_acc.as<int>();
+  a.row_of = s->bp_row_of.as<int>(); a.slot_batch = a.row_of + C; a.src_state = a.row_of + 2 * C; a.src_acc = s->bp_src_acc.as<int>();
+  {
+    int* bb = s->bp_batch.as<int>();
+    a.bat_id = bb; a.bat_iter = bb + C; a.bat_dl = bb + 2 * C; a.bat_grp = bb + 3 * C; a.bat_live = bb + 4 * C; a.bat_nfin = bb + 5 * C;
+    a.bat_longest_fin = bb + 6 * C; a.bat_longest_cur = bb + 7 * C; a.bat_state = bb + 8 * C; a.bat_given = bb + 9 * C;
+  }
+  a.cand_dl = s->bp_cand.as<int>(); a.cand_batch = a.cand_dl + j.MC;
   a.tok = s->bp_tok.as<int>(); a.drafts_all = s->bs_drafts_src.as<int>();
   a.cand_next = s->bs_cand_next.as<int64_t>(); a.len_next = s->bs_len_next.as<int>(); a.fin_next = s->bs_fin_next.as<uint8_t>();
   a.logp_next = s->bs_logp_next.as<float>(); a.parent = s->bs_parent.as<int>(); a.parent_draft = s->bs_parent_draft.as<int>();
   a.gen = s->gen.as<int>(); a.front = s->front.as<int>(); a.len = s->bs_len.as<int>(); a.active = s->bs_active.as<uint8_t>();
   a.finished = s->bs_fin.as<uint8_t>(); a.live = s->bs_mark.as<uint8_t>(); a.logp = s->bs_logp.as<float>(); a.per_cand = s->bs_per_cand.as<int>();
   a.drafts32 = s->drafts.as<int>();
-  a.sens = j.smart ? s->bp_sens.as<uint8_t>() : nullptr; a.chosen_slot = s->bs_best_slot.as<int>(); a.chosen = s->bs_chosen.as<int64_t>();
+  a.chosen_slot = s->bs_best_slot.as<int>(); a.chosen = s->bs_chosen.as<int64_t>();
   a.leaf_score = s->leaf_score.as<float>(); a.leaf_tok = s->leaf_tok.as<int>(); a.leaf_cnt = s->leaf_cnt.as<int>();
   a.cnt = s->bs_cnt.as<BeamCounters>(); a.io = reinterpret_cast<const BeamPoolIo*>(io_dev); a.host = dev_host; a.dev_summary = s->bp_grp.as<int>();
   hipLaunchKernelGGL(k_bsp_init, dim3(64), dim3(256), 0, st, a, s->t_src_of.as<int>(), s->bp_cand_len.as<int>());
@@ -1936,7 +1948,7 @@ static int bpool_admit(BeamPoolJob& j, const int64_t* d_src_rows, int ld_src, in
   if (!j.smart)      // make_drafts(src[:, 1:], draft_len, N, 5, 200) (:430): independent of how far the row is padded
     TTX_TRY(launch_make_drafts<int>(st, s->tok_src.as<int>(), Ls_new, 1, R, Ls_new - 1, j.N, j.D0, j.p.eos_token, j.p.pad_token,
                                     j.p.replace_token, s->drafts_new.as<int>()));
-  hipLaunchKernelGGL(k_bsp_admit, dim3(1), dim3(64), 0, st, j.a, s->bp_new_slot.as<int>(), s->bp_cand_len.as<int>(), R, first_row);
+  hipLaunchKernelGGL(k_bsp_admit, dim3(1), dim3(1), 0, st, j.a, s->bp_new_slot.as<int>(), s->bp_cand_len.as<int>(), R, first_row);
   HIP_TRY(hipGetLastError());
   BeamPoolFillArgs f{};
   f.new_slot = s->bp_new_slot.as<int>(); f.R = R; f.first_row = first_row;
@@ -1989,7 +2001,7 @@ static int bpool_enqueue_iter(const BeamPoolJob& j, int cur, int variant) {
   BeamHitsArgs ha{};
   ha.logits = s->logits.as<float>(); ha.V = V; ha.finished = s->bs_fin.as<uint8_t>(); ha.slot_of = s->t_slot_of.as<int>();
   ha.per_cand = s->bs_per_cand.as<int>(); ha.drafts32 = s->drafts.as<int>();
-  ha.n_cand = MC; ha.N = j.N; ha.dl = dl; ha.K = j.K; ha.nucleus = 0.9975f; ha.hit = s->bs_hit.as<uint8_t>();
+  ha.n_cand = MC; ha.N = j.N; ha.dl = dl; ha.K = j.K; ha.nucleus = 0.9975f; ha.hit = s->bs_hit.as<uint8_t>(); ha.dl_of = j.a.cand_dl;
   BeamLeaves2Args le{};
   le.logits = s->logits.as<float>(); le.V = V; le.finished = s->bs_fin.as<uint8_t>(); le.slot_of = s->t_slot_of.as<int>();
   le.per_cand = s->bs_per_cand.as<int>(); le.drafts32 = s->drafts.as<int>(); le.logp = s->bs_logp.as<float>();
@@ -1997,7 +2009,7 @@ static int bpool_enqueue_iter(const BeamPoolJob& j, int cur, int variant) {
   le.n_cand = MC; le.N = j.N; le.dl = dl; le.K = j.K; le.bos = j.p.bos_token; le.pad = j.p.pad_token; le.smart = j.smart ? 1 : 0;
   le.best_n = s->bs_best_n.as<int>(); le.best_slot = s->bs_best_slot.as<int>(); le.chosen = s->bs_chosen.as<int64_t>();
   le.leaf_score = s->leaf_score.as<float>(); le.leaf_tok = s->leaf_tok.as<int>(); le.leaf_cnt = s->leaf_cnt.as<int>();
-  le.live = s->bs_mark.as<uint8_t>(); le.pool_K = j.K; le.sens = j.smart ? s->bp_sens.as<uint8_t>() : nullptr;
+  le.live = s->bs_mark.as<uint8_t>(); le.dl_of = j.a.cand_dl; le.grp_of = j.a.bat_grp; le.cand_batch = j.a.cand_batch;
   const dim3 hits_grid(MC, cdiv(std::max(j.N * dl, 1), BS_HITS_WAVES));
   const size_t leaves_lds = (size_t)2 * (dl + 1) * 4;
   if (V <= 256) {
@@ -2018,7 +2030,9 @@ static int bpool_enqueue_iter(const BeamPoolJob& j, int cur, int variant) {
   }
   hipLaunchKernelGGL(k_bsp_select, dim3(j.C), dim3(256), lds, st, j.a);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_bsp_publish, dim3(1), dim3(64), 0, st, j.a);
+  hipLaunchKernelGGL(k_bsp_batches, dim3(cdiv(j.C, 256)), dim3(256), 0, st, j.a);
+  hipLaunchKernelGGL(k_bsp_retire, dim3(j.C), dim3(256), 0, st, j.a);
+  hipLaunchKernelGGL(k_bsp_publish, dim3(cdiv(j.C, 256)), dim3(256), 0, st, j.a);
   HIP_TRY(hipGetLastError());
   return TTX_OK;
 }
@@ -2066,50 +2080,58 @@ static int bpool_launch_iter(BeamPoolJob& j, int n_running) {
 }
 
 extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_sessions, const int64_t* d_src, int R_total, int Ls_all,
-                                                  const int32_t* h_len, const int32_t* h_given_ls, int capacity,
-                                                  const ttx_beam_params* p, int64_t* d_out, int16_t* d_trace_len, uint8_t* d_trace_grp,
-                                                  int32_t* d_summary, int trace_cap, ttx_beam_stats* stats, void* stream) {
-  if (!sessions || n_sessions <= 0 || !d_src || R_total < 0 || !h_len || !h_given_ls || capacity <= 0 || capacity > 1024 || !p || !d_out ||
-      !d_trace_len || !d_trace_grp || !d_summary || trace_cap <= 0 || trace_cap > 32000 || !stats)
+                                                  const int32_t* h_len, const int32_t* h_batch_of, int n_batches,
+                                                  const int32_t* h_given_ls, int capacity, const ttx_beam_params* p, int64_t* d_out,
+                                                  int16_t* d_trace_len, int32_t* d_summary, int trace_cap, ttx_beam_stats* stats,
+                                                  void* stream) {
+  if (!sessions || n_sessions <= 0 || !d_src || R_total < 0 || !h_len || !h_batch_of || n_batches < 0 || !h_given_ls || capacity <= 0 ||
+      capacity > 1024 || !p || !d_out || !d_trace_len || !d_summary || trace_cap <= 0 || trace_cap > 32000 || !stats)
     return fail(TTX_ERR_INVALID, "bad argument to ttx_beam_speculative_generate_pool");
   if (R_total == 0) return TTX_OK;
   for (int i = 0; i < n_sessions; ++i) { if (!sessions[i]) return fail(TTX_ERR_INVALID, "null session"); TTX_TRY(session_alive(sessions[i])); }
-  int len_max = 2;
-  for (int i = 0; i < R_total; ++i) {
+  // the work list: whole batches, in order; batch b owns the sources [first[b], first[b + 1])
+  std::vector<int> first(n_batches + 1, 0);
+  int len_max = 2, max_batch = 0;
+  for (int i = 0, b = -1; i < R_total; ++i) {
+    if (h_batch_of[i] != b) {
+      if (h_batch_of[i] != b + 1 || h_batch_of[i] >= n_batches) return fail(TTX_ERR_INVALID, "h_batch_of must number the batches 0, 1, ... in order");
+      b = h_batch_of[i];
+      first[b] = i;
+    }
+    first[b + 1] = i + 1;
     if (h_len[i] < 2 || h_len[i] > Ls_all) return fail(TTX_ERR_INVALID, "row length outside [2, width of the source matrix]");
-    if (h_given_ls[i] < h_len[i]) return fail(TTX_ERR_INVALID, "a source's given batch width is smaller than its length");
-    if (p->smart_drafts_mode && h_given_ls[i] - 5 <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
+    if (h_given_ls[b] < h_len[i]) return fail(TTX_ERR_INVALID, "a batch's given width is smaller than one of its sources");
+    if (p->smart_drafts_mode && h_given_ls[b] - 5 <= 0) return fail(TTX_ERR_REFERENCE, "The number of drafts must be greater than 0");
     len_max = std::max(len_max, (int)h_len[i]);
   }
+  if (R_total > 0 && h_batch_of[R_total - 1] != n_batches - 1) return fail(TTX_ERR_INVALID, "n_batches does not match h_batch_of");
+  for (int b = 0; b < n_batches; ++b) max_batch = std::max(max_batch, first[b + 1] - first[b]);
+  if (max_batch > capacity) return fail(TTX_ERR_INVALID, "a batch has more sources than the pool has slots");
   const ttx_config& c = sessions[0]->m->cfg;
   int Ls_cap = std::min(std::max(192, ((len_max + 63) / 64) * 64), c.max_positions);
   Ls_cap = std::max(Ls_cap, len_max);
   TTX_TRY(beam_validate(sessions[0], d_src, 1, Ls_cap, p, d_out));
-  const int Dreq = clamp_draft_len(p->draft_len, 5, 200);
-  const int D0 = p->smart_drafts_mode ? clamp_draft_len(Dreq + 1, 5, 200) - 1 : Dreq;
-  if (p->max_len - 2 < D0)       // the very first draft would be cut (:476): the per-source rule of the pool does not apply
-    return fail(TTX_ERR_INVALID, "the source pool needs max_len - 2 >= draft_len; decode the batches as given");
   HIP_TRY(hipSetDevice(sessions[0]->m->device));
   release_retired();
   EventGuard ready;
   HIP_TRY(hipEventCreateWithFlags(&ready.e, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(ready.e, (hipStream_t)stream));
-  const int n_jobs = std::min(n_sessions, cdiv(R_total, std::max(1, std::min(capacity / 2, 8))));
-  const int C = std::min(capacity, std::max(1, cdiv(R_total, n_jobs)));
+  const int n_jobs = std::max(1, std::min({n_sessions, n_batches, cdiv(R_total, std::max(1, std::min(capacity / 2, 8)))}));
+  const int C = std::min(capacity, std::max(max_batch, cdiv(R_total, n_jobs)));
   BeamPoolIo io{};
-  io.out = d_out; io.trace_len = d_trace_len; io.trace_grp = d_trace_grp; io.summary = d_summary; io.T_cap = trace_cap;
+  io.out = d_out; io.trace_len = d_trace_len; io.summary = d_summary; io.T_cap = trace_cap;
   std::vector<BeamPoolJob> jobs(n_jobs);
   int rc_final = TTX_OK;
   for (int i = 0; i < n_jobs && rc_final == TTX_OK; ++i) {
     ttx_session* s = sessions[i];
     if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamWaitEvent(s->own_stream, ready.e, 0));
-    rc_final = bpool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, io, h_len, h_given_ls, R_total);
+    rc_final = bpool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, io, h_len, h_batch_of, h_given_ls, R_total, n_batches);
   }
   int admit_div = 4;
   if (const char* e = getenv("TTX_POOL_ADMIT_DIV")) admit_div = std::max(1, atoi(e));
   const int min_admit = std::max(1, C / admit_div);
-  int cursor = 0, done = 0;
+  int cursor_b = 0, done = 0;                                  // next batch of the work list
   bool hung = false;
   ttx_beam_stats acc{};
   while (done < n_jobs && rc_final == TTX_OK) {
@@ -2123,36 +2145,46 @@ extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_
           if ((++j.idle_spins & 0xffff) == 0 && watchdog_expired(j.last_progress)) { rc_final = session_hung(s); hung = true; break; }
           continue;
         }
-        if (bh->error) { rc_final = fail(TTX_ERR_HIP, "source pool bookkeeping failed (admitted more sources than free slots)"); break; }
+        if (bh->error) { rc_final = fail(TTX_ERR_HIP, "batch pool bookkeeping failed (admitted more sources than free slots)"); break; }
         int n_live = (j.launched == 0 ? 0 : bh->n_live) + j.admitted_since;
         int n_running = (j.launched == 0 ? 0 : bh->n_running) + j.admitted_since;
         const int free_slots = C - n_live;
-        if (cursor < R_total && (n_live == 0 || free_slots >= min_admit)) {
-          // the last sources of the list are shared out over the pools still running, so that they drain together
+        if (cursor_b < n_batches && (n_live == 0 || free_slots >= std::max(min_admit, first[cursor_b + 1] - first[cursor_b]))) {
+          // whole batches, as many as fit; the last batches of the list are shared out over the pools still running, so that
+          // they drain together, and a first fill that fits the pools at once is split evenly
           int n_run_jobs = 0;
           for (const BeamPoolJob& o : jobs) n_run_jobs += (o.phase == 1);
-          const int remaining = R_total - cursor;
+          const int remaining = R_total - first[cursor_b];
           int share = std::max(1, cdiv(remaining, std::max(1, n_run_jobs)));
           if (j.launched == 0 && (long long)n_jobs * C >= R_total) share = std::max(1, cdiv(remaining, n_jobs - i));
-          const int take = std::min({free_slots, remaining, share});
-          int Ls_new = 2;
-          for (int r = cursor; r < cursor + take; ++r) Ls_new = std::max(Ls_new, (int)h_len[r]);
-          rc_final = bpool_admit(j, d_src + (size_t)cursor * Ls_all, Ls_all, take, Ls_new, cursor);
-          if (rc_final != TTX_OK) break;
-          cursor += take;
-          n_live += take;
-          n_running += take;
+          int take = 0, b_end = cursor_b;
+          while (b_end < n_batches) {
+            const int sz = first[b_end + 1] - first[b_end];
+            if (take + sz > free_slots || (take > 0 && take + sz > share)) break;
+            take += sz;
+            ++b_end;
+          }
+          if (take > 0) {
+            const int r_first = first[cursor_b];
+            int Ls_new = 2;
+            for (int r = r_first; r < r_first + take; ++r) Ls_new = std::max(Ls_new, (int)h_len[r]);
+            rc_final = bpool_admit(j, d_src + (size_t)r_first * Ls_all, Ls_all, take, Ls_new, r_first);
+            if (rc_final != TTX_OK) break;
+            cursor_b = b_end;
+            n_live += take;
+            n_running += take;
+          }
         }
         if (n_live == 0) {
           if (hipEventRecord(s->ev_c, j.st) != hipSuccess ||
               hipMemcpyAsync(s->host_state, s->bs_cnt.p, sizeof(BeamCounters), hipMemcpyDeviceToHost, j.st) != hipSuccess ||
               hipEventRecord(s->ev_done, j.st) != hipSuccess) {
-            rc_final = fail(TTX_ERR_HIP, "source pool: enqueueing the final counter read-back failed");
+            rc_final = fail(TTX_ERR_HIP, "batch pool: enqueueing the final counter read-back failed");
             break;
           }
           j.phase = 2;
         } else {
-          if (j.launched > (long long)(trace_cap + 2) * (R_total + 1)) { rc_final = fail(TTX_ERR_HIP, "source pool failed to terminate"); break; }
+          if (j.launched > (long long)(trace_cap + 2) * (R_total + 1)) { rc_final = fail(TTX_ERR_HIP, "batch pool failed to terminate"); break; }
           rc_final = bpool_launch_iter(j, n_running);
         }
         progressed = true;

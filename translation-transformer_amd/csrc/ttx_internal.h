@@ -84,7 +84,7 @@ struct ttx_session {
   // tree (beam) decoding
   Buf tk[2], tv[2], t_prev_len, t_slot_of, t_src_of;
   // beam-speculative source pool (continuous batching over sources of many batches)
-  Buf bp_row_of, bp_iter, bp_given_ls, bp_cand_len, bp_tok, bp_new_slot, bp_io, bp_sens, bp_grp, bp_src_acc, bp_enc_qkv;
+  Buf bp_row_of, bp_batch, bp_cand, bp_cand_len, bp_tok, bp_new_slot, bp_io, bp_grp, bp_src_acc, bp_enc_qkv;
   ttx::BeamPoolHost* bp_host = nullptr; // pinned + device-mapped, written by k_bsp_publish
   ttx::HostInfo* host_info = nullptr;   // pinned + device-mapped, written by the accept kernels
   hipStream_t own_stream = nullptr;     // the loops run on a session-owned stream (the caller's may be the null stream)
@@ -140,8 +140,8 @@ struct ttx_session {
                                  &snap_logits, &snap_act, &snap_front, &snap_gen, &snap_state, &leaf_score, &leaf_tok, &leaf_cnt,
                                  &beam_summary, &bs_cand_next, &bs_len_next, &bs_fin_next, &bs_logp_next, &bs_len, &bs_fin, &bs_active,
                                  &bs_logp, &bs_per_cand, &bs_best_n, &bs_best_slot, &bs_chosen, &bs_parent, &bs_parent_draft, &bs_mark,
-                                 &bs_drafts_src, &bs_cnt, &bs_hit, &bp_row_of, &bp_iter, &bp_given_ls, &bp_cand_len, &bp_tok, &bp_new_slot,
-                                 &bp_io, &bp_sens, &bp_grp, &bp_src_acc, &bp_enc_qkv}) { b->owner_gen = &alloc_generation; all.push_back(b); } }
+                                 &bs_drafts_src, &bs_cnt, &bs_hit, &bp_row_of, &bp_batch, &bp_cand, &bp_cand_len, &bp_tok, &bp_new_slot,
+                                 &bp_io, &bp_grp, &bp_src_acc, &bp_enc_qkv}) { b->owner_gen = &alloc_generation; all.push_back(b); } }
 };
 
 namespace ttx {

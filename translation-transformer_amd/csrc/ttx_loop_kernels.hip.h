@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void k_ragged_topk(RaggedTopkArgs a) {
 // Core of the leaf enumeration for one candidate `c` (the whole workgroup): `rowp(p)` = logits row of position p along
 // the candidate's chosen draft, `chosen(p)` = its p-th draft token.
 template <int VPL, class RowPtr, class Chosen>
-__device__ __forceinline__ void beam_leaves_core(int c, int nacc, float root, int dl, int V, int K, int bos, RowPtr rowp, Chosen chosen,
+__device__ __forceinline__ void beam_leaves_core(int c, int nacc, float root, int dl, int dl_logic, int V, int K, int bos, RowPtr rowp, Chosen chosen,
                                                  float* leaf_score, int* leaf_tok, int* leaf_cnt, float* lp_kept) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = (int)(blockDim.x >> 6);
   const int dl1 = dl + 1;
@@ -701,7 +701,7 @@ __device__ __forceinline__ void beam_leaves_core(int c, int nacc, float root, in
     int my_idx, nk;
     float my_val, m, z;
     topk_to_lanes<VPL>(row, V, 20.0f, K, lane, my_idx, my_val, nk, m, z);     // lane r: the rank-r logit (nucleus 20 keeps every rank)
-    const int excl = (p < nacc) ? chosen(p) : ((p < dl) ? bos : -1);
+    const int excl = (p < nacc) ? chosen(p) : ((p < dl_logic) ? bos : -1);     // dl_logic: the draft length in force (<= dl, the layout's)
     // survivors (not the excluded token, not an exact-zero logit) go out in ascending token id: a survivor's place is the
     // number of survivors with a smaller id
     const bool valid = lane < nk && my_idx != excl && my_val != 0.0f;
@@ -1070,6 +1070,7 @@ struct BeamHitsArgs {
   int n_cand, N, dl, K;
   float nucleus;
   uint8_t* hit;                                      // [max_cand, N * dl]: draft token inside the kept set of its position?
+  const int* dl_of;                                  // pool: [max_cand] draft length of the candidate's batch (<= dl, the row layout's); null: dl
 };
 
 // Acceptance test of every (draft, position) pair of every running candidate, one wave per pair, spread over the whole
@@ -1085,6 +1086,7 @@ __global__ __launch_bounds__(BS_HITS_WAVES * 64) void k_bs_hits(BeamHitsArgs a) 
   const int p = blockIdx.y * BS_HITS_WAVES + wave;
   if (p >= a.per_cand[c] * a.dl) return;
   const int i = p / a.dl, j = p % a.dl;
+  if (a.dl_of && j >= a.dl_of[c]) return;            // beyond the batch's (shrunk) draft: k_bs_leaves never looks there
   const int srow = (j == 0) ? 0 : 1 + i * a.dl + (j - 1);
   const float* row = a.logits + ((size_t)a.slot_of[c] * step_rps(a.N, a.dl) + srow) * a.V;
   const int tok = a.drafts32[((size_t)c * a.N + i) * a.dl + j];
@@ -1102,12 +1104,11 @@ struct BeamLeaves2Args {
   int n_cand, N, dl, K, bos, pad, smart;
   int* best_n; int* best_slot; int64_t* chosen;      // [max_cand], [max_cand], [max_cand, dl]
   float* leaf_score; int* leaf_tok; int* leaf_cnt;
-  // source pool (ttx_beam_speculative_generate_pool); all null / 0 on the per-batch path
+  // source pool (ttx_beam_speculative_generate_pool); all null on the per-batch path
   const uint8_t* live;     // [max_cand] 0: no candidate in this slot (its segments get no leaves)
-  int pool_K;              // candidates per source slot: in smart mode the -1-padded table is as wide as the SOURCE's longest
-                           // group (what the source would see alone in a batch), not the whole launch's
-  uint8_t* sens;           // [max_cand] smart mode: 1 if some wider table (up to N entries) would pick another draft — then the
-                           // candidate's outcome depends on the other sources of its given batch (scheduling.replay_beam_batch)
+  const int* dl_of;        // [max_cand] draft length in force for the candidate's batch (<= dl, the row layout's)
+  const int* grp_of;       // smart mode: [batch slots] longest draft group of each batch in this iteration (the width of the
+  const int* cand_batch;   //             -1-padded table the best draft is picked from, :779-784) and [max_cand] -> batch slot
 };
 
 // One workgroup per candidate.  (1) Accepted length of each of its drafts = leading hits of k_bs_hits (finished candidates
@@ -1133,38 +1134,23 @@ __global__ __launch_bounds__(BS_LEAVES_THREADS) void k_bs_leaves(BeamLeaves2Args
   }
   const int pc = a.per_cand[c];
   const bool fin = a.finished[c] != 0;
+  const int dl_c = a.dl_of ? a.dl_of[c] : a.dl;
   for (int i = threadIdx.x; i < pc; i += blockDim.x) {
     int ok = 0;
     if (!fin) {
       const uint8_t* h = a.hit + (size_t)c * a.N * a.dl + (size_t)i * a.dl;
-      while (ok < a.dl && h[ok]) ++ok;
+      while (ok < dl_c && h[ok]) ++ok;
     }
     s_nok[i] = ok;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int W = a.N;
-    if (a.smart && a.pool_K > 0) {
-      W = 1;
-      const int c0 = (c / a.pool_K) * a.pool_K;
-      for (int k = 0; k < a.pool_K; ++k) W = max(W, a.per_cand[c0 + k]);
-    } else if (a.smart) {
-      W = a.cnt->max_group;
-    }
+    const int W = !a.smart ? a.N : (a.grp_of ? a.grp_of[a.cand_batch[c]] : a.cnt->max_group);
     for (int i = 0; i < W; ++i) s_v[i] = (i < pc) ? (long long)s_nok[i] : -1ll;
     const int best = ttxsel::topk1_index(s_v, s_ix, W);
     s_best = best;
     a.best_n[c] = s_nok[best];
     a.best_slot[c] = best;
-    if (a.sens) {
-      uint8_t sv = 0;
-      if (a.smart && !fin)
-        for (int W2 = W + 1; W2 <= a.N && !sv; ++W2) {
-          for (int i = 0; i < W2; ++i) s_v[i] = (i < pc) ? (long long)s_nok[i] : -1ll;
-          if (ttxsel::topk1_index(s_v, s_ix, W2) != best) sv = 1;
-        }
-      a.sens[c] = sv;
-    }
   }
   __syncthreads();
   const int best = s_best;
@@ -1181,7 +1167,7 @@ __global__ __launch_bounds__(BS_LEAVES_THREADS) void k_bs_leaves(BeamLeaves2Args
   const int RPS = step_rps(a.N, a.dl);
   const float* base = a.logits + (size_t)a.slot_of[c] * RPS * a.V;
   const int* dr = a.drafts32 + ((size_t)c * a.N + best) * a.dl;
-  beam_leaves_core<VPL>(c, s_nok[best], a.logp[c], a.dl, a.V, a.K, a.bos,
+  beam_leaves_core<VPL>(c, s_nok[best], a.logp[c], a.dl, dl_c, a.V, a.K, a.bos,
                         [&](int p) { return base + (size_t)((p == 0) ? 0 : 1 + best * a.dl + (p - 1)) * a.V; },
                         [&](int p) { return dr[p]; },
                         a.leaf_score, a.leaf_tok, a.leaf_cnt, lp_kept);
@@ -1293,60 +1279,73 @@ __global__ __launch_bounds__(256) void k_beam_step(BeamStepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Beam-speculative SOURCE POOL (ttx_beam_speculative_generate_pool): continuous batching over the sources of many given
-// batches.  In the reference's loop the sources of a batch interact only through batch-wide scalars — the shared tensor width,
-// the draft length min(max_len - longest row - 1, draft_len) (:476/:671), the stop rule (every row holds EOS, :586) and, in
-// smart mode, the width of the -1-padded table the best draft is picked from (the batch's longest group, :779-784 -> :225) —
-// while a source's candidates, leaves, scores and selection depend on that source alone (and a source all of whose n_best rows
-// hold EOS is a fixed point of the iteration: one PAD leaf per row with log-prob + 0).  So every source is decoded under the
-// rule it would see ALONE in a batch, in a pool of C source slots (K = n_best candidate slots each) that is refilled from a
-// length-sorted work list as sources finish, one verify step per iteration over all live candidates (M ~ 10^4 step rows instead
-// of ~1.5 k), and per source and iteration the longest new row and the table-width data are recorded; the host then replays
-// the reference's batch loop over the batches AS GIVEN from those traces (scheduling.replay_beam_batch): output width, model
-// calls and counters come out exactly, and the rare batch whose scalars WOULD have coupled its sources (a row within
-// draft_len + 1 of max_len; a table-width-sensitive draft choice) is decoded again as given.
+// Beam-speculative BATCH POOL (ttx_beam_speculative_generate_pool): continuous batching over many given batches.
+// In the reference's loop (speculative_decoding.py:428-598, :600-845) the sources of a batch meet only in batch-wide scalars —
+// the draft length min(max_len - longest row - 1, draft_len) (:476 / :671), the stop rule (every row holds EOS, :586; or no
+// room left, :464), the tensor width, and in smart mode the width of the -1-padded table the best draft is picked from (the
+// batch's longest draft group, :779-784 -> :225) — while candidates, leaves, scores and the per-source selection depend on the
+// source alone, and a source all of whose n_best rows hold EOS is a fixed point of the iteration (one PAD leaf of log-prob + 0
+// per row, same order).  The pool therefore owns C source slots (K = n_best candidate slots each) and NB batch slots: a given
+// batch is admitted as a whole (its sources start together and stay in lock-step), ONE verify step per iteration serves every
+// live candidate of every batch in the pool (M ~ 10^4 step rows instead of ~1.5 k), and the batch-wide scalars are kept per
+// batch slot on the device, exactly as the reference computes them:
+//   bat_dl      the draft length in force (non-increasing; the step's row layout keeps draft_len slots per draft, a batch
+//               whose draft shrank simply stops looking beyond its own length)
+//   bat_grp     smart mode: the longest draft group of the batch's candidates in this iteration (finished sources count 1)
+//   stop        every source finished -> its slots are free; no room left -> its running sources are retired as they stand
+// A source whose K rows all hold EOS retires at once (its slots are reused by the next batch) and only its longest row stays
+// behind in the batch slot.  Per source the longest new row of every iteration is recorded, from which the host derives the
+// result width, the model calls and the counters of each given batch (scheduling.replay_beam_batch).
 //   iteration = k_bsp_prep -> k_tree_cache -> k_bs_list -> verify step -> k_bs_hits -> k_bs_leaves (pool arguments) ->
-//               k_bsp_select -> k_bsp_publish            (admission between iterations: k_bsp_admit -> k_bsp_fill)
-enum BeamPoolStatus { BP_RUNNING = 0, BP_DONE = 1, BP_ERR_LEAVES = 2, BP_IRREGULAR = 3, BP_MAX_STEPS = 4, BP_RUNAWAY = 5 };
+//               k_bsp_select -> k_bsp_batches -> k_bsp_retire -> k_bsp_publish      (admission: k_bsp_admit -> k_bsp_fill)
+enum BeamPoolStatus { BP_RUNNING = 0, BP_DONE = 1, BP_ERR_LEAVES = 2, BP_STOPPED = 3, BP_MAX_STEPS = 4 };
 
 struct BeamPoolHost { int steps_done; int n_live; int n_running; int error; };     // pinned, device-mapped: written by k_bsp_publish
 
 // Caller-side arrays of one pool call (device pointers; constant for the call), in work-list order.
 struct BeamPoolIo {
-  int64_t* out;              // [R_total][K][max_len]: the hypotheses of every finished source, best first, PAD beyond
+  int64_t* out;              // [R_total][K][max_len]: the hypotheses of every retired source, best first, PAD beyond
   short* trace_len;          // [R_total][T_cap]: longest hypothesis (tokens) of the source after each of its iterations
-  unsigned char* trace_grp;  // [R_total][T_cap]: smart mode: bits 0-6 the source's longest draft group, bit 7 choice-sensitive
   int* summary;              // [R_total][8]: iterations, BeamPoolStatus, input lines, running rows, accepted sum, accepted count,
                              //               longest hypothesis at the end, decoded candidates summed over the iterations
   const int* len_all;        // [R_total] source length (position after the last non-PAD token)
-  const int* given_all;      // [R_total] padded width of the batch the source was given in (smart mode: library size)
+  const int* batch_all;      // [R_total] index of the source's batch in the work list
+  const int* given_all;      // [n_batches] padded width of each given batch (smart mode: library size)
   int T_cap;
   int pad_;
 };
 
 struct BeamPoolArgs {
-  // slots
   int C, K, N, D0, Ls_cap, max_len, ld;          // ld: row stride of the candidate rows (max_len + D0 + 2)
   int smart, lib_ld, pad, bos, eos, repl, max_steps;
-  int* row_of; int* iter; int* given_ls; int* src_acc;      // [C], [C], [C], [C][8]
+  // source slots [C]
+  int* row_of; int* slot_batch; int* src_acc; int* src_state;    // src_acc [C][8]; src_state: BeamPoolStatus decided this iteration
   const int* tok;                                // [C][Ls_cap] source tokens per slot (PAD beyond the source)
   const int* drafts_all;                         // all drafts: [C][N][D0]
+  // batch slots [C] (a batch has at least one source)
+  int* bat_id; int* bat_iter; int* bat_dl; int* bat_grp; int* bat_live; int* bat_nfin; int* bat_longest_fin; int* bat_longest_cur;
+  int* bat_state; int* bat_given;
   // candidates ([C*K])
   int64_t* cand_next; int* len_next; uint8_t* fin_next; float* logp_next; int* parent; int* parent_draft;
   int* gen; int* front; int* len; uint8_t* active; uint8_t* finished; uint8_t* live; float* logp; int* per_cand; int* drafts32;
-  const uint8_t* sens; const int* chosen_slot; const int64_t* chosen;
+  int* cand_dl; int* cand_batch;
+  const int* chosen_slot; const int64_t* chosen;
   const float* leaf_score; const int* leaf_tok; const int* leaf_cnt;
-  BeamCounters* cnt; const BeamPoolIo* io; BeamPoolHost* host; int* dev_summary;   // dev_summary [4]: live, running, error, -
+  BeamCounters* cnt; const BeamPoolIo* io; BeamPoolHost* host; int* dev_summary;   // dev_summary [4]: live sources, running candidates, error, -
 };
 
 __global__ void k_bsp_init(BeamPoolArgs a, int* src_of, int* cand_src_len) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   const int MC = a.C * a.K;
-  for (int i = tid; i < a.C; i += nth) { a.row_of[i] = -1; a.iter[i] = 0; a.given_ls[i] = 0; }
+  for (int i = tid; i < a.C; i += nth) {
+    a.row_of[i] = -1; a.slot_batch[i] = 0; a.src_state[i] = BP_RUNNING;
+    a.bat_id[i] = -1; a.bat_iter[i] = 0; a.bat_dl[i] = a.D0; a.bat_grp[i] = 0; a.bat_live[i] = 0; a.bat_nfin[i] = 0;
+    a.bat_longest_fin[i] = 0; a.bat_longest_cur[i] = 0; a.bat_state[i] = 0; a.bat_given[i] = 0;
+  }
   for (int i = tid; i < a.C * 8; i += nth) a.src_acc[i] = 0;
   for (int i = tid; i < MC; i += nth) {
     a.len_next[i] = 1; a.fin_next[i] = 1; a.logp_next[i] = 0.f; a.parent[i] = -1; a.parent_draft[i] = 0;
-    a.active[i] = 0; a.finished[i] = 1; a.live[i] = 0; a.per_cand[i] = 0;
+    a.active[i] = 0; a.finished[i] = 1; a.live[i] = 0; a.per_cand[i] = 0; a.cand_dl[i] = a.D0; a.cand_batch[i] = 0;
     src_of[i] = i / a.K; cand_src_len[i] = 1;
   }
   if (tid == 0) {
@@ -1358,20 +1357,32 @@ __global__ void k_bsp_init(BeamPoolArgs a, int* src_of, int* cand_src_len) {
   }
 }
 
-// One block.  The R new sources (rows first_row .. first_row + R - 1 of the work list) take the lowest free slots in order.
-__global__ __launch_bounds__(256) void k_bsp_admit(BeamPoolArgs a, int* new_slot, int* cand_src_len, int R, int first_row) {
-  if (threadIdx.x != 0) return;
-  int got = 0;
-  for (int s = 0; s < a.C && got < R; ++s) {
-    if (a.row_of[s] >= 0) continue;
+// One thread.  The R new sources (rows first_row .. first_row + R - 1 of the work list: whole batches, in order) take the
+// lowest free source slots; every new batch takes the lowest free batch slot.
+__global__ void k_bsp_admit(BeamPoolArgs a, int* new_slot, int* cand_src_len, int R, int first_row) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const BeamPoolIo io = *a.io;
+  int got = 0, s = 0, b = 0, cur_batch = -1, cur_slot = -1;
+  for (; got < R; ++got) {
     const int row = first_row + got;
+    while (s < a.C && a.row_of[s] >= 0) ++s;
+    if (s >= a.C) break;
+    const int batch = io.batch_all[row];
+    if (batch != cur_batch) {
+      while (b < a.C && a.bat_id[b] >= 0) ++b;
+      if (b >= a.C) break;
+      cur_batch = batch; cur_slot = b;
+      a.bat_id[b] = batch; a.bat_iter[b] = 0; a.bat_dl[b] = min(a.D0, a.max_len - 2); a.bat_grp[b] = 0; a.bat_live[b] = 0; a.bat_nfin[b] = 0;   // :457, :476
+      a.bat_longest_fin[b] = 0; a.bat_longest_cur[b] = 0; a.bat_state[b] = 0; a.bat_given[b] = io.given_all[batch];
+    }
     new_slot[got] = s;
     a.row_of[s] = row;
-    a.iter[s] = 0;
-    a.given_ls[s] = a.io->given_all[row];
+    a.slot_batch[s] = cur_slot;
+    a.src_state[s] = BP_RUNNING;
+    a.bat_live[cur_slot] += 1;
     for (int q = 0; q < 8; ++q) a.src_acc[s * 8 + q] = 0;
-    for (int k = 0; k < a.K; ++k) cand_src_len[s * a.K + k] = a.io->len_all[row];
-    ++got;
+    for (int k = 0; k < a.K; ++k) { cand_src_len[s * a.K + k] = io.len_all[row]; a.cand_batch[s * a.K + k] = cur_slot; }
+    ++s;
   }
   // the host only admits as many sources as it knows to be free, so got == R
   if (got != R) { a.dev_summary[2] = 1; a.host->error = 1; __threadfence_system(); }
@@ -1409,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_bsp_fill(BeamPoolFillArgs a) {
     const size_t row = (size_t)(a.first_row + i);
     const BeamPoolIo io = *a.io;
     for (int c = t; c < a.K * a.max_len; c += blockDim.x) io.out[row * a.K * a.max_len + c] = a.pad;
-    for (int c = t; c < io.T_cap; c += blockDim.x) { io.trace_len[row * io.T_cap + c] = -1; io.trace_grp[row * io.T_cap + c] = 0; }
+    for (int c = t; c < io.T_cap; c += blockDim.x) io.trace_len[row * io.T_cap + c] = -1;
     for (int c = t; c < 8; c += blockDim.x) io.summary[row * 8 + c] = 0;
   } else {
     const int key = blockIdx.y - 1;
@@ -1420,17 +1431,18 @@ __global__ __launch_bounds__(256) void k_bsp_fill(BeamPoolFillArgs a) {
 }
 
 // One workgroup per candidate slot c = s * K + k: k_bs_prep for the pool.  A slot without a source, or a candidate index the
-// source does not have yet (a fresh source has ONE <BOS> candidate, :447-459), is dead: not decoded, no leaves.  Smart mode
-// reads the library straight from the source tokens: make_drafts(src, draft_len + 1, Ls - 5, ...) (:603-615) returns ALL
-// Ls - 5 stride-1 windows of the row padded to the GIVEN batch's width Ls, in order (it asks for as many drafts as there are
-// windows), with EOS / PAD replaced by the replace token — window i is tokens i .. i + lib_ld - 1.
+// source does not have yet (in its batch's first iteration a source has ONE <BOS> candidate, :447-459), is dead: not decoded,
+// no leaves.  Smart mode reads the library straight from the source tokens: make_drafts(src, draft_len + 1, Ls - 5, ...)
+// (:603-615) returns ALL Ls - 5 stride-1 windows of the row padded to the GIVEN batch's width Ls, in order (it asks for as
+// many drafts as there are windows), with EOS / PAD replaced by the replace token — window i is tokens i .. i + lib_ld - 1.
 __global__ __launch_bounds__(256) void k_bsp_prep(BeamPoolArgs a) {
   __shared__ int s_scan[256];
   __shared__ int s_match[BS_MAX_SLOTS];
   const int c = blockIdx.x, t = threadIdx.x;
   const int s = c / a.K, k = c - s * a.K;
   const int row_id = a.row_of[s];
-  const int beam = (row_id >= 0) ? (a.iter[s] == 0 ? 1 : a.K) : 0;
+  const int b = a.slot_batch[s];
+  const int beam = (row_id >= 0) ? (a.bat_iter[b] == 0 ? 1 : a.K) : 0;
   if (k >= beam) {
     if (t == 0) { a.active[c] = 0; a.finished[c] = 1; a.live[c] = 0; a.per_cand[c] = 0; a.len[c] = 1; a.front[c] = 0; }
     return;
@@ -1441,8 +1453,9 @@ __global__ __launch_bounds__(256) void k_bsp_prep(BeamPoolArgs a) {
   const int fin = a.fin_next[c];
   if (t == 0) {
     a.len[c] = lc; a.front[c] = lc - 1; a.finished[c] = (uint8_t)fin; a.active[c] = fin ? 0 : 1; a.live[c] = 1; a.logp[c] = a.logp_next[c];
+    a.cand_dl[c] = a.bat_dl[b];
   }
-  const int dl = a.D0;
+  const int dl = a.D0;                                // the step's row layout; the batch may look at fewer tokens (cand_dl)
   int* dst = a.drafts32 + (size_t)c * a.N * dl;
   if (!a.smart) {
     const int* src = a.drafts_all + (size_t)s * a.N * a.D0;
@@ -1452,7 +1465,7 @@ __global__ __launch_bounds__(256) void k_bsp_prep(BeamPoolArgs a) {
   }
   const int last = (int)row[lc - 1];
   const int* tk = a.tok + (size_t)s * a.Ls_cap;
-  const int n_lib = a.given_ls[s] - 5;
+  const int n_lib = a.bat_given[b] - 5;
   auto lib_tok = [&](int pos) {                      // token `pos` of the padded, service-token-free source row
     const int v = (pos < a.Ls_cap) ? tk[pos] : a.pad;
     return (v == a.eos || v == a.pad) ? a.repl : v;
@@ -1477,12 +1490,14 @@ __global__ __launch_bounds__(256) void k_bsp_prep(BeamPoolArgs a) {
     const int n = e / dl, j = e % dl;
     dst[e] = lib_tok(s_match[n < count ? n : 0] + 1 + j);
   }
-  if (t == 0) a.per_cand[c] = count;
+  if (t == 0) {
+    a.per_cand[c] = count;
+    atomicMax(&a.bat_grp[b], count);                  // the batch's longest draft group of this iteration (:779-784)
+  }
 }
 
 // One workgroup per source slot: k_beam_select for the pool (the n_best best leaves of the source's candidates and the new
-// rows), then the source's own bookkeeping: trace entry, sums, and — when every new row holds EOS, or the source can no longer
-// be decoded under the pool's rule — its hypotheses go to the caller's array and the slot is freed.
+// rows) and the source's iteration record; whether the source retires is decided per batch afterwards (k_bsp_batches).
 __global__ __launch_bounds__(256) void k_bsp_select(BeamPoolArgs a) {
   extern __shared__ float sh[];
   __shared__ int s_win[NUC_MAX_KEEP];
@@ -1491,7 +1506,8 @@ __global__ __launch_bounds__(256) void k_bsp_select(BeamPoolArgs a) {
   const int s = blockIdx.x, t = threadIdx.x;
   const int row_id = a.row_of[s];
   if (row_id < 0) return;
-  const int it0 = a.iter[s];
+  const int b = a.slot_batch[s];
+  const int it0 = a.bat_iter[b];
   const int beam = it0 == 0 ? 1 : a.K;
   const int dl = a.D0, dl1 = dl + 1, K = a.K;
   const int c0 = s * K;
@@ -1499,12 +1515,8 @@ __global__ __launch_bounds__(256) void k_bsp_select(BeamPoolArgs a) {
   if (t == 0) { s_eos = 0; s_maxreal = 0; s_accsum = 0; s_acccnt = 0; s_running_next = 0; }
   const bool enough = select_best_leaves(a.leaf_score, a.leaf_cnt, seg0, beam * dl1, K, sh, s_win, s_wsc);   // ends with a barrier
   const BeamPoolIo io = *a.io;
-  int status = BP_RUNNING;
-  if (!enough) {
-    status = BP_ERR_LEAVES;
-  } else {
-    // the K new rows: root tokens, the kept draft tokens, the leaf token (the rows of c0 .. c0 + K - 1 are rewritten in place
-    // of the NEXT buffer; the roots are read from `gen`, which k_bsp_prep copied)
+  if (enough) {
+    // the K new rows: root tokens, the kept draft tokens, the leaf token (the roots are read from `gen`, which k_bsp_prep copied)
     for (int e = t; e < K * a.ld; e += blockDim.x) {
       const int r = e / a.ld, col = e - r * a.ld;
       const int sel = s_win[r];
@@ -1518,8 +1530,6 @@ __global__ __launch_bounds__(256) void k_bsp_select(BeamPoolArgs a) {
       if (j >= 0 && j <= dl) v = (j < p) ? a.chosen[(size_t)c * dl + j] : (j == p ? (int64_t)tok : (int64_t)a.pad);
       a.cand_next[(size_t)(c0 + r) * a.ld + col] = v;
     }
-    // per new row: score, parent, length, EOS flag (read every root's state BEFORE any of the next-iteration arrays of this
-    // source is overwritten: they are distinct arrays, `len`/`finished` vs `len_next`/`fin_next`)
     for (int r = t; r < K; r += blockDim.x) {
       const int sel = s_win[r];
       const int seg = sel / K, i = sel % K;
@@ -1541,56 +1551,82 @@ __global__ __launch_bounds__(256) void k_bsp_select(BeamPoolArgs a) {
     }
   }
   __syncthreads();
-  // the source's iteration record
-  const int it = it0 + 1;
-  int lines = 0, running = 0, grp = 0, sens = 0, run_cands = 0;
   if (t == 0) {
+    const int it = it0 + 1;
+    int lines = 0, running = 0, run_cands = 0;
     for (int k = 0; k < beam; ++k) {
       const int pc = a.per_cand[c0 + k];
       lines += pc;
       if (!a.finished[c0 + k]) { running += pc; ++run_cands; }
-      grp = max(grp, pc);
-      if (a.sens) sens |= a.sens[c0 + k];
     }
     int* acc = a.src_acc + s * 8;
-    acc[0] += lines; acc[1] += running; acc[2] += s_accsum; acc[3] += s_acccnt; acc[4] += run_cands;
-    if (it - 1 < io.T_cap) {
-      io.trace_len[(size_t)row_id * io.T_cap + it - 1] = (short)s_maxreal;
-      io.trace_grp[(size_t)row_id * io.T_cap + it - 1] = (unsigned char)((grp & 0x7f) | (sens ? 0x80 : 0));
-    }
-    if (status == BP_RUNNING) {
-      if (s_eos == K) status = BP_DONE;                                              // :586 for a batch of this source alone
-      else if (s_maxreal > a.max_len - 1 - a.D0) status = BP_IRREGULAR;              // the next draft would be shorter (:476)
-      else if (a.max_steps > 0 && it >= a.max_steps) status = BP_MAX_STEPS;
-      else if (it >= io.T_cap) status = BP_RUNAWAY;
-    }
-    a.iter[s] = it;
-    s_eos = status;                                    // broadcast
+    acc[0] += lines; acc[1] += running; acc[2] += s_accsum; acc[3] += s_acccnt; acc[4] += run_cands; acc[5] = s_maxreal; acc[6] = s_running_next;
+    if (it - 1 < io.T_cap) io.trace_len[(size_t)row_id * io.T_cap + it - 1] = (short)s_maxreal;
+    int st = BP_RUNNING;
+    if (!enough) { st = BP_ERR_LEAVES; atomicMax(&a.bat_state[b], 2); }       // the reference asserts for the whole batch (:195)
+    else if (s_eos == K) st = BP_DONE;
+    a.src_state[s] = st;
+    if (enough) atomicMax(&a.bat_longest_cur[b], s_maxreal);
   }
-  __syncthreads();
-  status = s_eos;
-  if (status == BP_RUNNING) {
-    if (t == 0) { atomicAdd(&a.dev_summary[0], 1); atomicAdd(&a.dev_summary[1], s_running_next); }
+}
+
+// One thread per batch slot: the reference's loop scalars of every batch in the pool after this iteration (:578-598):
+// longest row (finished sources included), room, the next draft length, and whether the loop goes on.
+__global__ void k_bsp_batches(BeamPoolArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.C || a.bat_id[b] < 0) return;
+  const int it = a.bat_iter[b] + 1;
+  a.bat_iter[b] = it;
+  if (a.bat_state[b] == 2) return;                               // error: its sources retire with BP_ERR_LEAVES
+  const int longest = max(a.bat_longest_fin[b], a.bat_longest_cur[b]);
+  const int room = a.max_len - longest - 1;                      // possible_draft_len (:596)
+  if (room < 1) a.bat_state[b] = 1;                              // `while possible_draft_len >= 1` (:464) ends the loop
+  else if (a.max_steps > 0 && it >= a.max_steps) a.bat_state[b] = 3;   // guard (not in the reference) — unless everything finished
+  a.bat_dl[b] = min(room < 1 ? 1 : room, a.bat_dl[b]);           // :476 for the next iteration
+  a.bat_longest_cur[b] = 0;
+}
+
+// One workgroup per source slot: sources that finished (every row holds EOS) or whose batch stopped hand their hypotheses and
+// their summary to the caller's arrays and free the slot; the last source of a batch frees the batch slot.
+__global__ __launch_bounds__(256) void k_bsp_retire(BeamPoolArgs a) {
+  const int s = blockIdx.x, t = threadIdx.x;
+  const int row_id = a.row_of[s];
+  if (row_id < 0) return;
+  const int b = a.slot_batch[s];
+  const int bst = a.bat_state[b];
+  int st = a.src_state[s];
+  // a finished source stays finished whatever happens to its batch later; a running one follows its batch
+  if (st == BP_RUNNING) st = (bst == 1) ? BP_STOPPED : (bst == 2) ? BP_ERR_LEAVES : (bst == 3) ? BP_MAX_STEPS : BP_RUNNING;
+  else if (st == BP_DONE && bst == 2) st = BP_ERR_LEAVES;         // the batch raised in this very iteration
+  const int* acc = a.src_acc + s * 8;
+  if (st == BP_RUNNING) {
+    if (t == 0) { atomicAdd(&a.dev_summary[0], 1); atomicAdd(&a.dev_summary[1], acc[6]); }
     return;
   }
-  // retire: hypotheses (a finished source only) and the summary go to the caller's arrays, the slot is free again
-  if (status == BP_DONE)
+  const BeamPoolIo io = *a.io;
+  const int K = a.K;
+  if (st == BP_DONE || st == BP_STOPPED)
     for (int e = t; e < K * a.max_len; e += blockDim.x) {
       const int r = e / a.max_len, col = e - r * a.max_len;
-      io.out[((size_t)row_id * K + r) * a.max_len + col] = a.cand_next[(size_t)(c0 + r) * a.ld + col];
+      io.out[((size_t)row_id * K + r) * a.max_len + col] = a.cand_next[(size_t)(s * K + r) * a.ld + col];
     }
   if (t == 0) {
-    const int* acc = a.src_acc + s * 8;
     int* sm = io.summary + (size_t)row_id * 8;
-    sm[0] = it; sm[1] = status; sm[2] = acc[0]; sm[3] = acc[1]; sm[4] = acc[2]; sm[5] = acc[3]; sm[6] = s_maxreal; sm[7] = acc[4];
+    sm[0] = a.bat_iter[b]; sm[1] = st; sm[2] = acc[0]; sm[3] = acc[1]; sm[4] = acc[2]; sm[5] = acc[3]; sm[6] = acc[5]; sm[7] = acc[4];
     a.row_of[s] = -1;
+    atomicMax(&a.bat_longest_fin[b], acc[5]);                     // a finished source's rows stay in the batch's tensor
+    atomicAdd(&a.bat_nfin[b], 1);
+    if (atomicSub(&a.bat_live[b], 1) == 1) a.bat_id[b] = -1;      // last source of the batch: the batch slot is free
   }
 }
 
 // Last kernel of an iteration: live sources / running candidates of the NEXT iteration and the iteration count go to the
-// pinned words the host polls; the device-side tallies are reset for the next iteration.
+// pinned words the host polls; per-iteration tallies are reset (smart mode: a batch with finished sources starts its longest
+// draft group at 1 — a finished row has exactly one draft, :417).
 __global__ void k_bsp_publish(BeamPoolArgs a) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < a.C) a.bat_grp[b] = (a.bat_id[b] >= 0 && a.bat_nfin[b] > 0) ? 1 : 0;
+  if (b == 0) {
     a.host->n_live = a.dev_summary[0];
     a.host->n_running = a.dev_summary[1];
     if (a.dev_summary[2]) a.host->error = 1;

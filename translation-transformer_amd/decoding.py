@@ -415,13 +415,12 @@ class TranslationInferenceBeamSearchSpeculative:
                       capacity: int | None = None) -> list:
         """Several batches on the GPU at once; every returned tensor and the counters are those of per-batch ``generate`` calls.
 
-        ``pool`` (default: on for two or more batches, ``TTX_BEAM_POOL=0`` turns it off): the SOURCES of all given batches are
-        decoded in slot pools — continuous batching, one verify step per iteration over a few hundred candidates of many
-        batches (ttx_beam_speculative_generate_pool) — and the reference's loop is replayed per given batch from per-source
-        traces (scheduling.replay_beam_batch); a batch whose batch-wide scalars would have coupled its sources (a hypothesis
-        within draft_len + 1 of max_len, a table-width-sensitive draft tie in smart mode) or on which the reference raises is
-        decoded again as given.  Otherwise the batches run as given, ``in_flight`` of them at once, one session + stream each
-        (ttx_beam_speculative_generate_many).
+        ``pool`` (default: on for two or more batches, ``TTX_BEAM_POOL=0`` turns it off): the given batches are decoded in slot
+        pools — continuous batching: whole batches are admitted as slots free up, one verify step per iteration serves a few
+        hundred candidates of many batches, and the reference's batch-wide loop scalars (draft length, stop rule, smart-mode
+        table width) are kept per batch on the device (ttx_beam_speculative_generate_pool); result width, model calls and
+        counters per given batch come from per-source traces (scheduling.replay_beam_batch).  Otherwise the batches run as
+        given, ``in_flight`` of them at once, one session + stream each (ttx_beam_speculative_generate_many).
 
         ``on_error="skip"``: a batch on which the reference raises (or the ``max_steps`` guard trips) yields ``None`` instead of
         ending the call; the indices are kept in ``self.last_failed_batches`` — ``generate`` on that batch raises the error."""
@@ -437,10 +436,9 @@ class TranslationInferenceBeamSearchSpeculative:
             m.check_tokens(b)
         if pool is None:
             pool = len(srcs) > 1 and os.environ.get("TTX_BEAM_POOL", "1") != "0"
-        # the pool's per-source rule needs the first draft uncut (max_len - 2 >= draft_len, :476) and, in smart mode, a window
-        # library for every batch (Ls - 5 > 0, drafting.py:39)
+        # smart mode needs a window library for every batch (Ls - 5 > 0, drafting.py:39); max_len < 3 never enters the loop
         d0 = self.draft_len if not self.smart_drafts_mode else min(max(5, self.draft_len + 1), 200) - 1
-        if pool and self.max_len - 2 >= d0 and all(int(b.shape[1]) >= 2 and (not self.smart_drafts_mode or int(b.shape[1]) > 5) for b in srcs):
+        if pool and self.max_len >= 3 and all(int(b.shape[1]) >= 2 and (not self.smart_drafts_mode or int(b.shape[1]) > 5) for b in srcs):
             return self._generate_pooled(srcs, in_flight, on_error, capacity, d0)
         return self._generate_as_given(srcs, list(range(len(srcs))), in_flight, on_error)
 
@@ -481,27 +479,31 @@ class TranslationInferenceBeamSearchSpeculative:
     def _generate_pooled(self, srcs: list, in_flight: int, on_error: str, capacity: int | None, d0: int) -> list:
         from .scheduling import replay_beam_batch
         m, K, L = self.model, self.n_best, self.max_len
-        sizes = [int(s.shape[0]) for s in srcs]
-        R = sum(sizes)
-        Lmax = max(int(s.shape[1]) for s in srcs)
+        n = len(srcs)
+        sizes = np.array([int(s.shape[0]) for s in srcs])
+        widths = np.array([int(s.shape[1]) for s in srcs], dtype=np.int32)
+        R = int(sizes.sum())
+        Lmax = int(widths.max())
         allsrc = torch.full((R, Lmax), self.pad_token_idx, dtype=torch.int64, device=m.device)
-        given = np.empty(R, dtype=np.int32)
-        r0 = 0
-        for s in srcs:
+        starts = np.concatenate([[0], np.cumsum(sizes)])
+        for s, r0 in zip(srcs, starts):
             allsrc[r0:r0 + s.shape[0], :s.shape[1]] = s
-            given[r0:r0 + s.shape[0]] = s.shape[1]
-            r0 += s.shape[0]
         pos = torch.arange(1, Lmax + 1, device=m.device)
         lengths = ((allsrc != self.pad_token_idx) * pos).amax(dim=1).clamp(min=2).cpu().numpy().astype(np.int32)
-        order = np.argsort(-lengths, kind="stable")                 # longest first: a chunk is encoded at its longest row's width
+        # work list: whole batches, the one with the longest source first (a chunk is encoded at its longest row's width)
+        batch_long = np.array([lengths[starts[i]:starts[i + 1]].max() for i in range(n)])
+        border = np.argsort(-batch_long, kind="stable")
+        order = np.concatenate([np.arange(starts[b], starts[b + 1]) for b in border])
         order_t = torch.from_numpy(order).to(m.device)
         width = int(lengths.max())
         src_mat = allsrc[order_t][:, :width].contiguous()
         h_len = np.ascontiguousarray(lengths[order])
-        h_given = np.ascontiguousarray(given[order])
+        h_batch = np.ascontiguousarray(np.repeat(np.arange(n, dtype=np.int32), sizes[border]))
+        h_given = np.ascontiguousarray(widths[border])
         # pool size: about 16 k step rows per iteration (where the step GEMMs run on their large tilings); a few pools in flight
         rps = 1 + self.requested_drafts_num * d0
         cap = int(capacity or os.environ.get("TTX_BEAM_POOL_CAPACITY") or max(4, min(512, 16384 // max(1, K * rps))))
+        cap = max(cap, int(sizes.max()))
         n_sess = max(1, min(in_flight, 4, -(-R // cap)))
         if os.environ.get("TTX_POOL_SESSIONS"):
             n_sess = max(1, int(os.environ["TTX_POOL_SESSIONS"]))
@@ -510,18 +512,18 @@ class TranslationInferenceBeamSearchSpeculative:
         T_cap = L + 8
         out_sorted = torch.empty((R, K, L), dtype=torch.int64, device=m.device)
         tlen = torch.empty((R, T_cap), dtype=torch.int16, device=m.device)
-        tgrp = torch.empty((R, T_cap), dtype=torch.uint8, device=m.device)
         summ = torch.empty((R, 8), dtype=torch.int32, device=m.device)
         st = N.BeamStats()
         p = self._params()
+        i32 = C.POINTER(C.c_int32)
         N.check(m._lib.ttx_beam_speculative_generate_pool(
-            sess, len(sessions), src_mat.data_ptr(), R, width, h_len.ctypes.data_as(C.POINTER(C.c_int32)),
-            h_given.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(p), out_sorted.data_ptr(), tlen.data_ptr(), tgrp.data_ptr(),
-            summ.data_ptr(), T_cap, C.byref(st), m._stream()))
+            sess, len(sessions), src_mat.data_ptr(), R, width, h_len.ctypes.data_as(i32), h_batch.ctypes.data_as(i32), n,
+            h_given.ctypes.data_as(i32), cap, C.byref(p), out_sorted.data_ptr(), tlen.data_ptr(), summ.data_ptr(), T_cap, C.byref(st),
+            m._stream()))
         inv = torch.empty_like(order_t)
         inv[order_t] = torch.arange(R, device=m.device)
         out_rows = out_sorted[inv]
-        tlen_h, tgrp_h, summ_h = tlen[inv].cpu().numpy(), tgrp[inv].cpu().numpy(), summ[inv].cpu().numpy()
+        tlen_h, summ_h = tlen[inv].cpu().numpy(), summ[inv].cpu().numpy()
         # what the device executed (for bench.py's roofline), once for the whole call
         t = self.stats_total
         for k in ("verified_positions", "executed_positions", "kv_prefix_positions", "running_candidates", "src_tokens_padded",
@@ -530,31 +532,28 @@ class TranslationInferenceBeamSearchSpeculative:
         t["src_positions"] += int((summ_h[:, 7].astype(np.int64) * lengths.astype(np.int64)).sum())   # cross-attention keys read
         t["device_model_calls"] = t.get("device_model_calls", 0) + int(st.model_calls)
         t["pool_calls"] = t.get("pool_calls", 0) + 1
-        res: list = [None] * len(srcs)
-        again = []
-        r0 = 0
-        for bi, B in enumerate(sizes):
-            rep = replay_beam_batch(tlen_h[r0:r0 + B], tgrp_h[r0:r0 + B], summ_h[r0:r0 + B], L, d0, K, bool(self.smart_drafts_mode))
-            if rep.as_given:
-                again.append(bi)
+        res: list = [None] * n
+        for bi in range(n):
+            r0, r1 = int(starts[bi]), int(starts[bi + 1])
+            rep = replay_beam_batch(tlen_h[r0:r1], summ_h[r0:r1], L, d0, K)
+            if rep.error is not None:
+                if on_error == "raise":
+                    if rep.error == "max_steps":
+                        raise RuntimeError("beam-speculative loop exceeded max_steps (non-terminating input)")
+                    raise N.ReferenceError_(f"batch {bi}: fewer candidate leaves than n_best for a source (the reference asserts here, "
+                                            "speculative_decoding.py:195)")
+                self.last_failed_batches.append(bi)
+                continue
+            res[bi] = out_rows[r0:r1, :, :rep.out_width].contiguous()
+            before = self._counter_values()
+            self.model_calls_num += rep.model_calls
+            self.accepted_tokens_num += rep.accepted_tokens
+            self.produced_non_pad_tokens += rep.produced_non_pad_tokens
+            if self.smart_drafts_mode:
+                self.model_input_lines_num += rep.input_lines
+                self.b_sz += rep.running_rows
             else:
-                res[bi] = out_rows[r0:r0 + B, :, :rep.out_width].contiguous()
-                before = self._counter_values()
-                self.model_calls_num += rep.model_calls
-                self.accepted_tokens_num += rep.accepted_tokens
-                self.produced_non_pad_tokens += rep.produced_non_pad_tokens
-                if self.smart_drafts_mode:
-                    self.model_input_lines_num += rep.input_lines
-                    self.b_sz += rep.running_rows
-                else:
-                    self.n_drafts += B * self.requested_drafts_num
-                self.last_batch_counters[bi] = {k: v - before[k] for k, v in self._counter_values().items()}
-                t["batches"] += 1
-            r0 += B
-        t["batches_decoded_as_given"] = t.get("batches_decoded_as_given", 0) + len(again)
-        if again:
-            redo = self._generate_as_given([srcs[i] for i in again], again, in_flight, on_error)
-            for i, o in zip(again, redo):
-                res[i] = o
+                self.n_drafts += (r1 - r0) * self.requested_drafts_num
+            self.last_batch_counters[bi] = {k: v - before[k] for k, v in self._counter_values().items()}
+            t["batches"] += 1
         return res
-

@@ -79,28 +79,23 @@ def plan_row_groups(lengths, group_size: int):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Part 2 — beam-speculative sources (ttx_beam_speculative_generate_pool).
+# Part 2 — beam-speculative batches (ttx_beam_speculative_generate_pool).
 #
-# In `TranslationInferenceBeamSearchSpeculative.generate_*` (src/decoding/speculative_decoding.py:428-598, :600-845) the
-# sources of a batch meet in four batch-wide scalars only:
-#   * the tensor width: it grows to (longest row) + draft_len + 1 before every iteration (:488-491 / :679-686);
-#   * the draft length min(max_len - longest row - 1, draft_len) (:476 / :671) — equal to draft_len for every source as long
-#     as no row of the batch is within draft_len + 1 of max_len;
-#   * the stop rule: all b_size * n_best rows hold EOS (:586 / :826), or no room is left (:464 / :652);
-#   * smart mode: the best draft of a candidate is topk(1) over its accepted lengths padded with -1 to the LONGEST draft group
-#     of the batch (:779-784 -> topk_in_each_group :225) — torch's CPU top-k breaks ties differently for different widths.
-# Candidates, leaves, log-probs and the per-source top-n_best selection of a source depend on that source alone, and a source
-# all of whose rows hold EOS is a fixed point of the iteration (one PAD leaf of log-prob +0 per row, same order).  So each
-# source is decoded as if alone, with per-iteration traces (longest new row; longest draft group and whether a wider table
-# would change a choice), and this function derives what the reference does with the batch AS GIVEN — or says that the
-# batch's scalars would have coupled its sources, in which case the caller decodes that batch as given.
+# The pool decodes the sources of a given batch in lock-step and keeps the batch-wide scalars of
+# `TranslationInferenceBeamSearchSpeculative.generate_*` (src/decoding/speculative_decoding.py:428-598, :600-845) on the device:
+# the draft length min(max_len - longest row - 1, draft_len) (:476 / :671), the stop rule (all rows hold EOS, :586 / :826; no
+# room left, :464 / :652) and, in smart mode, the longest draft group (:779-784).  What is left for the host is what the
+# reference derives from the shared TENSOR of the batch: its width, which grows to (longest row) + draft length + 1 before
+# every iteration (:488-491 / :679-686), the number of iterations, and the counters — a source that finished (and gave its
+# slots back) is a fixed point of the loop and keeps contributing n_best one-draft rows per iteration to
+# `model_input_lines_num` (smart mode, :741) until its batch ends.
 
-BP_DONE, BP_ERR_LEAVES, BP_IRREGULAR, BP_MAX_STEPS, BP_RUNAWAY = 1, 2, 3, 4, 5      # BeamPoolStatus (csrc/ttx_loop_kernels.hip.h)
+BP_DONE, BP_ERR_LEAVES, BP_STOPPED, BP_MAX_STEPS = 1, 2, 3, 4      # BeamPoolStatus (csrc/ttx_loop_kernels.hip.h)
 
 
 @dataclass
 class BeamBatchReplay:
-    as_given: bool            # True: decode this batch with the per-batch entry point (coupled scalars, or an error to raise)
+    error: str | None         # None, "reference" (fewer leaves than n_best for a source: the reference asserts, :195) or "max_steps"
     model_calls: int = 0      # iterations of the reference's loop on this batch
     out_width: int = 0        # columns of the tensor the reference returns
     accepted_tokens: int = 0
@@ -109,40 +104,32 @@ class BeamBatchReplay:
     running_rows: int = 0     # smart mode: of those, rows of unfinished candidates (b_sz)
 
 
-def replay_beam_batch(trace_len: np.ndarray, trace_grp: np.ndarray, summary: np.ndarray, max_len: int, draft_len: int,
-                      n_best: int, smart: bool) -> BeamBatchReplay:
-    """trace_len int [B, T_cap]: longest hypothesis of source b after its t-th iteration (column t - 1); trace_grp uint8
-    [B, T_cap]: bits 0-6 the source's longest draft group in that iteration, bit 7 "a wider table picks another draft";
-    summary int [B, 8]: iterations, status, input lines, running rows, accepted sum, accepted count, ... per source;
-    draft_len: the loop's draft length (the clamped one; smart mode: tokens after the key token)."""
+def replay_beam_batch(trace_len: np.ndarray, summary: np.ndarray, max_len: int, draft_len: int, n_best: int) -> BeamBatchReplay:
+    """trace_len int [B, T_cap]: longest hypothesis of source b after its t-th iteration (column t - 1); summary int [B, 8]:
+    iterations, status, input lines, running rows, accepted sum, accepted count, ... per source; draft_len: the loop's initial
+    draft length (the clamped one; smart mode: tokens after the key token)."""
     summary = np.asarray(summary).astype(np.int64)
     B = summary.shape[0]
     T_s, status = summary[:, 0], summary[:, 1]
-    if (status != BP_DONE).any():
-        return BeamBatchReplay(True)           # the reference asserts / the guard trips / a row nears max_len: as given
+    if (status == BP_ERR_LEAVES).any():
+        return BeamBatchReplay("reference")
+    if (status == BP_MAX_STEPS).any():
+        return BeamBatchReplay("max_steps")
+    if not np.isin(status, (BP_DONE, BP_STOPPED)).all():
+        raise ValueError("a source of this batch was never retired by the pool")
     T = int(T_s.max())
     tl = np.asarray(trace_len).astype(np.int64)[:, :T]
-    t_idx = np.arange(T)[None, :]
-    alive = t_idx < T_s[:, None]                                               # source b takes part in iteration t + 1 on its own
+    alive = np.arange(T)[None, :] < T_s[:, None]                               # source b took part in iteration t + 1
     last = tl[np.arange(B), T_s - 1][:, None]
     longest = np.where(alive, tl, last)                                        # a finished source keeps its rows
-    if (longest[alive] < 1).any():
+    if (longest < 1).any():
         raise ValueError("source trace shorter than its iteration count")
     batch_longest = longest.max(axis=0)                                        # after iteration t + 1
-    # every iteration but the last is followed by another one, whose draft must still be draft_len long (:476)
-    if T > 1 and (batch_longest[:-1] > max_len - 1 - draft_len).any():
-        return BeamBatchReplay(True)
-    if smart:
-        tg = np.asarray(trace_grp).astype(np.int64)[:, :T]
-        grp = np.where(alive, tg & 0x7f, 1)                                     # finished source: one draft per row
-        sens = alive & ((tg & 0x80) != 0)
-        batch_grp = grp.max(axis=0)[None, :]
-        if (sens & (grp != batch_grp)).any():
-            return BeamBatchReplay(True)
-    width, prev = 1, 1
+    width, prev, dl = 1, 1, draft_len
     for t in range(T):
-        width = max(width, prev + draft_len + 1)
+        dl = min(max_len - prev - 1, dl)                                        # :476 / :671
+        width = max(width, prev + dl + 1)                                       # :488-491: width += max(0, dl + 1 - empty columns)
         prev = int(batch_longest[t])
     acc = int(summary[:, 4].sum())
-    return BeamBatchReplay(False, T, width, acc, acc + int(summary[:, 5].sum()),
+    return BeamBatchReplay(None, T, width, acc, acc + int(summary[:, 5].sum()),
                            int(summary[:, 2].sum() + ((T - T_s) * n_best).sum()), int(summary[:, 3].sum()))
