@@ -314,11 +314,11 @@ int  ttx_tokenizer_decode(const ttx_tokenizer* t, const int64_t* ids, int n, cha
 int ttx_debug_step_snapshot(ttx_session* s, int32_t* info, float* h_logits, int32_t* h_act, int32_t* h_front,
                             int32_t* h_gen);
 
-/* Timing of the dominant kernel for bench.py's roofline: summed HIP-event time (events recorded on the
- * launch stream around every GEMM launch) and launch count of the generate calls on this session since the
- * previous read (reading resets the sums); `empty_pair_ms` is what one event pair with no kernel in between measures on the same stream (the
- * bracketing overhead contained in every launch's figure).  Only collected when the session was created with
- * TTX_PROFILE_GEMM=1 in the environment (that session launches eagerly, without graphs). */
+/* Timing of the dominant kernel for bench.py's roofline: summed HIP-event time (events recorded on the launch stream around
+ * every GEMM launch) and launch count of the generate calls on this session since the previous read (reading resets the sums);
+ * `empty_pair_ms` is what the bracketing adds to a launch's figure, calibrated on the same stream with pairs around a kernel of
+ * known duration (pair time minus the realtime ticks the kernel saw go by; median of 32).  Only collected when the session was
+ * created with TTX_PROFILE_GEMM=1 in the environment (that session launches eagerly, without graphs). */
 int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms);
 
 /* Development aid (tools/bench_gemm.py): times one GEMM shape (K = 64, 128 or a multiple of 256) in isolation on random

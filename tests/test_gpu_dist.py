@@ -77,7 +77,7 @@ def test_blob_broadcast_over_rccl():
 
 
 def test_two_rank_bench_data_path_equals_single_process(tmp_path):
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), here with both ranks on GPU 0:
+    """`python bench.py --gpus 2` without a launcher (it starts one process per rank itself), here with both ranks on GPU 0:
     shard bounds, weight broadcast, per-rank decode through the slot pools, prediction gather, counter sums.  The gathered
     predictions must equal a single-process per-batch decode of the same rows with the same weights."""
     import translation_transformer_amd as tta
@@ -91,11 +91,13 @@ def test_two_rank_bench_data_path_equals_single_process(tmp_path):
         torch.save(train("mit", steps=200, device="cuda", verbose=False, n_train=4000), weights)
     steps, warmup, bs, world = 3, 1, 32, 2
     dump = tmp_path / "gathered.npy"
-    env = dict(os.environ, TTX_SHARE_GPU="1", TTX_DIST_BACKEND="gloo", TTX_WEIGHTS=str(weights), TTX_DUMP_PREDICTIONS=str(dump),
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup",
-           str(warmup), "--timed-only"]
+    # plain `python bench.py --gpus 2`: no launcher, no WORLD_SIZE — bench.py starts the two ranks itself (before touching a GPU);
+    # TTX_SHARE_GPU=1 lets both use GPU 0 (rehearsal on a 1-GPU box; collectives then run over gloo)
+    env = dict(os.environ, TTX_SHARE_GPU="1", TTX_WEIGHTS=str(weights), TTX_DUMP_PREDICTIONS=str(dump), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup), "--timed-only"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.strip().split("\n") if l.startswith("{")][-1])
@@ -121,3 +123,12 @@ def test_two_rank_bench_data_path_equals_single_process(tmp_path):
     finished = int((exp == SEOS).any(axis=2).sum())
     print(f"two-rank rehearsal: {finished}/{exp.shape[0]} rows decode to EOS (weights: {'1500-step cache' if trained else '200 steps'})")
     assert finished > (0.5 * exp.shape[0] if trained else 0)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """--gpus N on a box with fewer devices (and no TTX_SHARE_GPU) exits non-zero instead of printing an n_gpus: 1 line."""
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TTX_SHARE_GPU")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--timed-only"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert r.returncode != 0 and "n_gpus" not in r.stdout

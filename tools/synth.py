@@ -123,3 +123,24 @@ def batches(rows: list[list[int]], batch_size: int):
     dataloader + pad_sequence collate produce (seq2seq_wrappers.py:121-127,168-175)."""
     for i in range(0, len(rows), batch_size):
         yield pad_batch(rows[i:i + batch_size])
+
+
+def smiles_vocabulary() -> dict:
+    """A token string for every id of the synthetic vocabulary, so that the string side of the pipeline (regex tokenizer,
+    collate, detokenizer, CSV writer: src/data_handling/tokenizer_smiles.py:8,34-39, tokenizer_base.py:80-94,
+    src/callbacks.py:49-64) can be driven with the same reactions: {token string: id} like the reference's vocab.json read
+    back (tokenizer_base.py:60-66).  Every string is ONE token of the reference's SMILES regex whatever its neighbours are
+    (single-character atoms / bonds / ring digits, two-digit ring closures %NN, bracket atoms), so decode(ids) tokenizes
+    back to the same ids."""
+    singles = list("NOSPFIbcnosp()=#-+\\/:~@>*$") + [str(d) for d in range(10)]      # '.', 'c' placed below; '?' is <UNK>
+    toks = {"<PAD>": PAD, "<BOS>": BOS, "<EOS>": EOS, "?": UNK, "c": C_TOK, ".": DOT, "(": BRANCH, "=": BOND}
+    pool = [t for t in singles if t not in toks] + ["Cl", "Br", "C", "B"] + [f"%{i:02d}" for i in range(100)]
+    elems = ["C", "N", "O", "S", "P", "Si", "B", "Se", "Na", "K", "Li", "Mg", "Zn", "Cu", "Pd", "Sn"]
+    decor = ["@H", "@@H", "H", "+", "-", "H2", "H3", "H+", "2+", ":1", ":2", ":3"]
+    pool += [f"[{e}{d}]" for d in decor for e in elems]
+    ids = [i for i in range(FIRST_REGULAR, V)]
+    assert len(pool) >= len(ids) and len(set(pool)) == len(pool)
+    for i, t in zip(ids, pool):
+        toks[t] = i
+    assert len(toks) == V
+    return toks

@@ -861,19 +861,31 @@ static void collect_gemm_profile(ttx_session* s, hipStream_t st) {
     if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) s->prof_ms += ms;
   }
   s->ev_used = 0;
-  // what an empty event pair costs on this stream (no kernel between the two records): reported beside the raw sum
-  if (s->prof_empty_pair_ms < 0 && s->ev_pool.size() >= 64) {
-    for (int i = 0; i < 64; ++i) {
-      (void)hipEventRecord(s->ev_pool[i].first, st);
-      (void)hipEventRecord(s->ev_pool[i].second, st);
+  // What the bracketing itself adds to a launch's figure: pairs around a kernel of known duration (k_spin reports the
+  // realtime ticks it saw go by), pair time minus in-kernel time, median of 32.
+  if (s->prof_empty_pair_ms < 0 && s->ev_pool.size() >= 32) {
+    unsigned long long* d_ticks = nullptr;
+    if (hipMalloc(&d_ticks, 32 * sizeof(unsigned long long)) == hipSuccess) {
+      for (int i = 0; i < 32; ++i) {
+        (void)hipEventRecord(s->ev_pool[i].first, st);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, d_ticks + i, 2000);          // 20 us
+        (void)hipEventRecord(s->ev_pool[i].second, st);
+      }
+      (void)hipStreamSynchronize(st);
+      unsigned long long h_ticks[32];
+      std::vector<double> over;
+      if (hipMemcpy(h_ticks, d_ticks, sizeof(h_ticks), hipMemcpyDeviceToHost) == hipSuccess)
+        for (int i = 0; i < 32; ++i) {
+          float ms = 0.f;
+          if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess)
+            over.push_back((double)ms - (double)h_ticks[i] * 1e-5);                        // 100 MHz ticks -> ms
+        }
+      (void)hipFree(d_ticks);
+      if (!over.empty()) {
+        std::sort(over.begin(), over.end());
+        s->prof_empty_pair_ms = std::max(0.0, over[over.size() / 2]);
+      }
     }
-    (void)hipStreamSynchronize(st);
-    double acc = 0;
-    for (int i = 0; i < 64; ++i) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second) == hipSuccess) acc += ms;
-    }
-    s->prof_empty_pair_ms = acc / 64.0;
   }
 }
 
@@ -2132,6 +2144,7 @@ extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_
   if (const char* e = getenv("TTX_POOL_ADMIT_DIV")) admit_div = std::max(1, atoi(e));
   const int min_admit = std::max(1, C / admit_div);
   int cursor_b = 0, done = 0;                                  // next batch of the work list
+  const auto t_call = std::chrono::steady_clock::now();
   bool hung = false;
   ttx_beam_stats acc{};
   while (done < n_jobs && rc_final == TTX_OK) {
@@ -2185,6 +2198,10 @@ extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_
           j.phase = 2;
         } else {
           if (j.launched > (long long)(trace_cap + 2) * (R_total + 1)) { rc_final = fail(TTX_ERR_HIP, "batch pool failed to terminate"); break; }
+          if (s->host_timing)
+            fprintf(stderr, "[ttx pool %d] t=%.3f ms iteration %d: %d live sources, %d running candidates, next batch %d of %d\n", i,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), j.launched + 1, n_live,
+                    n_running, cursor_b, n_batches);
           rc_final = bpool_launch_iter(j, n_running);
         }
         progressed = true;

@@ -1279,6 +1279,16 @@ __global__ __launch_bounds__(256) void k_beam_step(BeamStepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Calibration of bench.py's per-launch HIP event pairs: a kernel of KNOWN duration (it waits `ticks` of the 100 MHz realtime
+// counter and reports what it saw elapse) between two events — pair time minus in-kernel time is what the bracketing costs.
+__global__ void k_spin(unsigned long long* out, int ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t1 = t0;
+  while ((long long)(t1 - t0) < (long long)ticks) t1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Beam-speculative BATCH POOL (ttx_beam_speculative_generate_pool): continuous batching over many given batches.
 // In the reference's loop (speculative_decoding.py:428-598, :600-845) the sources of a batch meet only in batch-wide scalars —
 // the draft length min(max_len - longest row - 1, draft_len) (:476 / :671), the stop rule (every row holds EOS, :586; or no

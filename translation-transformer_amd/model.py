@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import _native as N
@@ -122,6 +123,19 @@ class NativeTransformer:
         while len(pool) < n:
             pool.append(self.new_session())
         return pool[:n]
+
+    def kernel_profile(self) -> dict:
+        """GEMM event-pair sums of every session of this model since the last read (ttx_last_kernel_profile; sessions created
+        under TTX_PROFILE_GEMM=1): {"gemm_ms", "launches", "pair_overhead_ms"}."""
+        ms, n, e = C.c_double(), C.c_int64(), C.c_double()
+        tot_ms, tot_n, over = 0.0, 0, []
+        for sess in (getattr(self, "_pool", None) or [self._session]):
+            N.check(self._lib.ttx_last_kernel_profile(sess, C.byref(ms), C.byref(n), C.byref(e)))
+            tot_ms += ms.value
+            tot_n += n.value
+            if n.value and e.value > 0:
+                over.append(e.value)
+        return {"gemm_ms": tot_ms, "launches": tot_n, "pair_overhead_ms": float(np.median(over)) if over else 0.0}
 
     def close(self) -> None:
         for extra in getattr(self, "_pool", [])[1:]:
