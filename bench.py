@@ -581,6 +581,8 @@ def measure_c2(ctx: Ctx, a, tta) -> dict:
                                           f"oracle/ (full-prefix recompute like the reference), torch {torch.__version__} fp32",
                                 "seconds": cpu_s, "model_calls": og.model_calls_num}
         line["parity"] = {"rows_token_identical_to_oracle": rows_same, "rows_checked": n_cpu, "batches_identical": same}
+    model.close()                         # sessions and workspaces of this measurement go back before the next one starts
+    torch.cuda.empty_cache()
     return line
 
 
@@ -721,6 +723,8 @@ def measure_beam(ctx: Ctx, a, tta, name: str, steps: int, warmup: int, full: boo
                                "seconds": cpu_s, "model_calls": og.model_calls_num}
         rec["parity"] = {"top1_rows_token_identical_to_oracle": top1, "rows_checked": n_cpu,
                          "hypotheses_token_identical_to_oracle": all_ranks, "hypotheses_checked": total}
+    model.close()
+    torch.cuda.empty_cache()
     return rec
 
 

@@ -322,7 +322,7 @@ int ttx_debug_step_snapshot(ttx_session* s, int32_t* info, float* h_logits, int3
 int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms);
 
 /* Development aid (tools/bench_gemm.py): times one GEMM shape (K = 64, 128 or a multiple of 256) in isolation on random
- * operands.  variant 2 / 46 / 4 = 64x64, 128x64, 128x128 tiles; 24 = the production kernel's own choice from the row count;
+ * operands.  variant 2 / 46 = 64x64, 128x64 tiles; 24 = the production kernel's own choice from the row count;
  * 3 = one wave per canonical slice (32x32 tiles, K = 256); 8 = one workgroup per slice with `splits` raw slabs (FFN2).  Returns
  * microseconds per launch over `reps` back-to-back launches and the largest absolute difference to the 64x64 tiling's result
  * — 0.0 for every variant: all of them evaluate the same ordered sum of K slices (csrc/ttx_gemm.hip). */

@@ -1,7 +1,7 @@
 """GEMM shapes of the verify step in isolation (ttx_debug_gemm_bench): microseconds per launch, TFLOP/s and the largest
 absolute difference to the 64x64 tiling's result — which must be 0.0 for every variant: all of them evaluate the canonical
 slice sum of translation-transformer_amd/csrc/ttx_gemm.hip.
-Variants: 2 = 64x64 tiles, 46 = 128x64, 4 = 128x128 (k_gemm_wide), 24 = k_gemm24's own choice from the row count,
+Variants: 2 = 64x64 tiles, 46 = 128x64, 24 = k_gemm24's own choice from the row count,
 3 = one wave per slice (32x32 tiles, K = 256), 8 = one workgroup per slice + slabs (FFN2).
 Usage: python tools/bench_gemm.py [M ...]"""
 import ctypes as C
@@ -15,8 +15,8 @@ st, cfg = tiny_state()
 m = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
 lib = m._lib
 Ms = [int(x) for x in sys.argv[1:]] or [15872, 7936, 4960, 2480, 992, 310]
-shapes = [("FFN1", 2048, 256, (2, 46, 4, 24)), ("QKV", 768, 256, (2, 46, 24, 3)), ("dxd", 256, 256, (2, 46, 24, 3)),
-          ("cls", 256, 256, (24, 3)), ("FFN2", 256, 2048, (2, 46, 4, 24, 8))]
+shapes = [("FFN1", 2048, 256, (2, 46, 24)), ("QKV", 768, 256, (2, 46, 24, 3)), ("dxd", 256, 256, (2, 46, 24, 3)),
+          ("FFN2", 256, 2048, (2, 46, 24, 8))]
 worst = 0.0
 for M in Ms:
     for name, N, K, variants in shapes:

@@ -267,7 +267,6 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   s->profile = pf && pf[0] == '1';
   // experiments: where the host switches between the bit-identical GEMM variants / tilings
   if (const char* e = getenv("TTX_SMALL_ROWS")) s->small_rows = std::max(0, atoi(e));
-  if (const char* e = getenv("TTX_WIDE_ROWS")) s->wide_rows = std::max(0, atoi(e));
   if (const char* e = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(e));
   if (const char* e = getenv("TTX_ATTN_SPLIT")) s->attn_split = atoi(e);
   if (const char* e = getenv("TTX_ATTN_FALLBACK")) s->attn_fallback = atoi(e) != 0;
@@ -310,8 +309,7 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
 // GEMM variant of a launch (ttx_internal.h: all variants return identical bits).  Steps: by live rows; bulk passes
 // (encoder, cross K/V, full-prefix decoder) by their row count.
 static int variant_for_rows(const ttx_session* s, long long rows, bool step) {
-  if (step && rows < s->small_rows) return GV_SMALL;
-  return rows >= s->wide_rows ? GV_WIDE : GV_BIG;
+  return (step && rows < s->small_rows) ? GV_SMALL : GV_BIG;
 }
 
 // d-wide GEMM -> slab(s) -> k_finish_ln: Y = LN2?(LN((resid + bias) + X W^T))

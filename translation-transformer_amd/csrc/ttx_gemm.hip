@@ -172,7 +172,7 @@ __device__ __forceinline__ void fold_slice(f32x16& tot, f32x16& acc, bool first)
   }
 }
 
-constexpr int G24_SMEM_FLOATS = 2 * 2 * 128 * 36;      // 73 728 B: the larger of the two tilings' LDS images
+constexpr int G24_SMEM_FLOATS = 2 * 2 * 64 * 68;       // 69 632 B: the larger of the two tilings' LDS images (64x64: two buffers of A and B, 64 x 68 each; 128x64: 2 x (128 + 64) x 36)
 
 // NT = number of 64-deep K tiles per workgroup when it is 1, 2 or 4 (straight-line code, every tile
 // requested up front); NT = 0: any multiple of 4 tiles, ring slots refilled as they drain.
@@ -298,23 +298,21 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 128-row tiles for launches with thousands of rows (slot pools: M up to ~16 000 step rows; encoder / cross-K/V bulk
-// passes): 128x128 output tile per workgroup, 2x2 waves of 64x64 (four independent 32x32 fp32-MFMA accumulators
-// per wave, so back-to-back MFMAs never wait on each other), 32-deep K tiles, LDS double buffer (stride 36 floats:
-// conflict-free ds_read_b128), one barrier per tile.  Against the 64x64 kernel: half the L2->LDS bytes and half the
-// LDS->register bytes per MFMA, 4 096 MFMA cycles per wave between barriers instead of 2 048.  The next tile's
-// global loads are issued before the MFMA block of the current one and written to the other LDS buffer BETWEEN the MFMAs
-// of the following tile (loads are unconditional, tile index clamped: counted vmcnt waits).
-// BN = 128: 2x2 waves of 64x64 (four accumulators per wave).  BN = 64: 2x2 waves of 64x32 (two accumulators per wave, one B
-// fragment): twice the workgroups for the launches that are short of them (N <= 768 at a few thousand rows), so that two
-// are resident per CU and one's prologue / epilogue overlaps the other's MFMAs.
+// 128x64 tiles for launches with thousands of rows (slot pools: M up to ~16 000 step rows; encoder / cross-K/V bulk
+// passes): 2x2 waves of 64x32 (two independent 32x32 fp32-MFMA accumulators per wave, so back-to-back MFMAs never wait on
+// each other), 32-deep K tiles, LDS double buffer (stride 36 floats: conflict-free ds_read_b128), one barrier per tile, two
+// workgroups per CU so that one's prologue / epilogue overlaps the other's MFMAs.  Against the 64x64 kernel: fewer L2->LDS
+// and LDS->register bytes per MFMA.  The next tile's global loads are issued before the MFMA block of the current one and
+// written to the other LDS buffer BETWEEN the MFMAs of the following tile (loads are unconditional, tile index clamped:
+// counted vmcnt waits).  (A 128x128 tiling — four accumulators per wave — was the fastest for FFN1 / FFN2 at >= 8 000 rows
+// while one chain per element was the arithmetic; with the running slice AND the folded total it needs more than the 256
+// registers two workgroups per CU leave each wave and loses to this one: profiles/r03_gemm_bench_canonical_slices.txt, v4.)
 // Canonical slices: a pair of 32-deep tiles is one 64-k slice; the accumulators are folded into the totals after every
-// slice_k / 64 pairs (fp32 adds issued while the other accumulators' MFMAs are still in the pipe).
-struct G4Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
+// slice_k / 64 pairs.
+struct G4Frag { float4 a0, a1, a2, a3, b0, b1; };
 
-template <int BN>
 __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const int bx, const int by, const int bz, float* smem) {
-  constexpr int BM = 128, BK = 32, LDT = BK + 4;
+  constexpr int BM = 128, BN = 64, BK = 32, LDT = BK + 4;
   constexpr int WN = BN / 2;                      // columns per wave
   typedef float (*TileBufsA)[BM * LDT];
   typedef float (*TileBufsB)[BN * LDT];
@@ -332,12 +330,11 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
   const int r = lane & 31, h = lane >> 5;
 
   const float* xp[4];
-  const float* wp[4];
+  const float* wp[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    xp[i] = a.X + (size_t)min(m0 + lr + 32 * i, M - 1) * a.ldx + kbeg + lc;
-    wp[i] = a.W + (size_t)min(n0 + min(lr + 32 * i, BN - 1), a.N - 1) * a.ldw + kbeg + lc;
-  }
+  for (int i = 0; i < 4; ++i) xp[i] = a.X + (size_t)min(m0 + lr + 32 * i, M - 1) * a.ldx + kbeg + lc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) wp[i] = a.W + (size_t)min(n0 + lr + 32 * i, a.N - 1) * a.ldw + kbeg + lc;
   auto gload = [&](int tile) {
     G4Frag f;
     const int ko = tile * BK;
@@ -347,10 +344,6 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     f.a3 = *reinterpret_cast<const float4*>(xp[3] + ko);
     f.b0 = *reinterpret_cast<const float4*>(wp[0] + ko);
     f.b1 = *reinterpret_cast<const float4*>(wp[1] + ko);
-    if constexpr (BN == 128) {
-      f.b2 = *reinterpret_cast<const float4*>(wp[2] + ko);
-      f.b3 = *reinterpret_cast<const float4*>(wp[3] + ko);
-    }
     return f;
   };
   auto lstore = [&](const G4Frag& f, int buf) {
@@ -362,21 +355,17 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     *reinterpret_cast<float4*>(as + 96 * LDT) = f.a3;
     *reinterpret_cast<float4*>(bs) = f.b0;
     *reinterpret_cast<float4*>(bs + 32 * LDT) = f.b1;
-    if constexpr (BN == 128) {
-      *reinterpret_cast<float4*>(bs + 64 * LDT) = f.b2;
-      *reinterpret_cast<float4*>(bs + 96 * LDT) = f.b3;
-    }
   };
 
-  f32x16 c00, c01, c10, c11;      // the running slice
-  f32x16 t00, t01, t10, t11;      // the folded total of the finished slices
+  f32x16 c00, c10;                // the running slice
+  f32x16 t00, t10;                // the folded total of the finished slices
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; t00[i] = 0.f; t01[i] = 0.f; t10[i] = 0.f; t11[i] = 0.f; }
+  for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c10[i] = 0.f; t00[i] = 0.f; t10[i] = 0.f; }
   const int aoff = (wm * 64 + r) * LDT + 4 * h, boff = (wn * WN + r) * LDT + 4 * h;
 
-  // One 32-deep K tile: 16 MFMAs per 8 k's.  `during(q)` (q = 0..3) runs after the first MFMA group of every 8-k
-  // step: the LDS writes of the NEXT tile go there, between MFMAs, so that they cost no MFMA time (the matrix pipe runs
-  // on while the wave issues them).
+  // One 32-deep K tile: 8 MFMAs per 8 k's.  `during(q)` (q = 0..3) runs after the first MFMA pair of every 8-k step: the
+  // LDS writes of the NEXT tile go there, between MFMAs, so that they cost no MFMA time (the matrix pipe runs on while the
+  // wave issues them).
   auto mma = [&](int buf, auto&& during) {
     const float* ap = As[buf] + aoff;
     const float* bp = Bs[buf] + boff;
@@ -384,72 +373,48 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     float4 a0 = *reinterpret_cast<const float4*>(ap);
     float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDT);
     float4 b0 = *reinterpret_cast<const float4*>(bp);
-    float4 b1 = b0;
-    if constexpr (BN == 128) b1 = *reinterpret_cast<const float4*>(bp + 32 * LDT);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 8) {
-      float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+      float4 na0 = a0, na1 = a1, nb0 = b0;
       if (kk + 8 < BK) {
         na0 = *reinterpret_cast<const float4*>(ap + kk + 8);
         na1 = *reinterpret_cast<const float4*>(ap + 32 * LDT + kk + 8);
         nb0 = *reinterpret_cast<const float4*>(bp + kk + 8);
-        if constexpr (BN == 128) nb1 = *reinterpret_cast<const float4*>(bp + 32 * LDT + kk + 8);
       }
-      if constexpr (BN == 128) {
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, c11, 0, 0, 0);
-        during(kk >> 3);
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, c11, 0, 0, 0);
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, c11, 0, 0, 0);
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, c11, 0, 0, 0);
-      } else {
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
-        during(kk >> 3);
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, c10, 0, 0, 0);
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
-      }
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
+      during(kk >> 3);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, c10, 0, 0, 0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0;
     }
   };
-  // quarter q of a tile's LDS writes (two float4 of A's 128 rows, one or two of B's rows)
+  // quarter q of a tile's LDS writes (one float4 of A's 128 rows per quarter, B's 64 rows in the first two)
   auto lstore_q = [&](const G4Frag& f, int buf, int q) {
     float* as = As[buf] + lr * LDT + lc;
     float* bs = Bs[buf] + lr * LDT + lc;
     if (q == 0) { *reinterpret_cast<float4*>(as) = f.a0; *reinterpret_cast<float4*>(bs) = f.b0; }
     else if (q == 1) { *reinterpret_cast<float4*>(as + 32 * LDT) = f.a1; *reinterpret_cast<float4*>(bs + 32 * LDT) = f.b1; }
-    else if (q == 2) { *reinterpret_cast<float4*>(as + 64 * LDT) = f.a2; if constexpr (BN == 128) *reinterpret_cast<float4*>(bs + 64 * LDT) = f.b2; }
-    else { *reinterpret_cast<float4*>(as + 96 * LDT) = f.a3; if constexpr (BN == 128) *reinterpret_cast<float4*>(bs + 96 * LDT) = f.b3; }
+    else if (q == 2) *reinterpret_cast<float4*>(as + 64 * LDT) = f.a2;
+    else *reinterpret_cast<float4*>(as + 96 * LDT) = f.a3;
   };
   // two register tiles in flight (static slots, clamped refills: same shape as the 64x64 kernel's ring): a tile's loads are
-  // issued two MFMA blocks (~3.4 us) before its LDS write.  The K range is a multiple of 64: ntiles is even.
+  // issued two MFMA blocks before its LDS write.  The K range is a multiple of 64: ntiles is even.
   const int last = ntiles - 1;
   const int bcol = n0 + wn * WN + r;
-  // the bias values are requested before the K loop (a load still pending in the epilogue would make every predicated
-  // store wait for vmcnt(0), i.e. for the previous store: 64 serialised round trips)
+  // the bias value is requested before the K loop (a load still pending in the epilogue would make every predicated store
+  // wait for vmcnt(0), i.e. for the previous store: 32 serialised round trips)
   const float bias0 = (!a.raw && a.bias) ? a.bias[min(bcol, a.N - 1)] : 0.f;
-  const float bias1 = (!a.raw && a.bias && BN == 128) ? a.bias[min(bcol + 32, a.N - 1)] : 0.f;
   const int pairs_per_slice = a.slice_k > 0 ? a.slice_k / (2 * BK) : 0;
   const bool sliced = pairs_per_slice > 0 && 2 * pairs_per_slice < ntiles;
   int pairs = 0;
   asm volatile("" ::: "memory");
   G4Frag f0 = gload(0);
-  asm volatile("" ::: "memory");        // issue order f0 then f1 also ahead of the loop: the header waits with vmcnt(8), not 0
+  asm volatile("" ::: "memory");        // issue order f0 then f1 also ahead of the loop: the header waits with a counted vmcnt, not 0
   G4Frag f1 = gload(1);
   // Tile i is computed from one LDS buffer while tile i + 1 is written into the other BETWEEN the MFMAs (after the
   // barrier that ends a phase every wave has finished reading the buffer the next phase overwrites), and the registers
@@ -472,19 +437,18 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
       const bool first = pairs == pairs_per_slice;
       fold_slice(t00, c00, first);
       fold_slice(t10, c10, first);
-      if constexpr (BN == 128) { fold_slice(t01, c01, first); fold_slice(t11, c11, first); }
     }
     __syncthreads();
   }
-  if (sliced) { c00 = t00; c10 = t10; if constexpr (BN == 128) { c01 = t01; c11 = t11; } }
+  if (sliced) { c00 = t00; c10 = t10; }
 
   float* Y = a.Y + (a.raw ? (size_t)bz * a.slab_stride : 0);
   const float lo = a.relu ? 0.f : -INFINITY;
-  auto store_tile = [&](const f32x16& c, int tm, int tn, float bv) {
-    const int col = n0 + wn * WN + tn * 32 + r;
+  auto store_tile = [&](const f32x16& c, int tm) {
+    const int col = n0 + wn * WN + r;
     float val[16];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) val[v] = fmaxf(c[v] + bv, lo);
+    for (int v = 0; v < 16; ++v) val[v] = fmaxf(c[v] + bias0, lo);
     const int row0 = m0 + wm * 64 + tm * 32 + 4 * h;
     float* yp = Y + (size_t)row0 * a.ldy + col;
     if (m0 + BM <= M && n0 + BN <= a.N) {            // interior workgroup (uniform): straight-line stores
@@ -499,10 +463,8 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
       }
     }
   };
-  store_tile(c00, 0, 0, bias0);
-  if constexpr (BN == 128) store_tile(c01, 0, 1, bias1);
-  store_tile(c10, 1, 0, bias0);
-  if constexpr (BN == 128) store_tile(c11, 1, 1, bias1);
+  store_tile(c00, 0);
+  store_tile(c10, 1);
 }
 
 // The first tiles of the whole grid in dispatch order take the work (all K slabs included): the dispatcher hands
@@ -533,23 +495,10 @@ __global__ __launch_bounds__(256) void k_gemm24(GemmArgs a) {
   if (a.big_min_tiles > 0 && mid_tiles >= a.big_min_tiles) {
     int bx, by, slab;
     if (!tile_of_workgroup(mid_tiles, nbx, nby, bx, by, slab)) return;
-    g4_body<64>(a, M, bx, by, slab, smem);
+    g4_body(a, M, bx, by, slab, smem);
   } else {
     g2_body<NT>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
   }
-}
-
-// 128x128 tiles as a kernel of their own (grid laid out for them): with the running slice AND the folded total of four
-// accumulators per wave it needs more than the 256 registers two workgroups per CU leave each wave, so it runs one workgroup
-// per CU — in-kernel stamps of round 2 put the MFMA share of a K tile at 82 % alone on a CU against 83 % when two share it —
-// and is chosen by the host (GV_WIDE) for the wide / deep shapes of steps with many thousands of live rows.
-__global__ __launch_bounds__(256) void k_gemm_wide(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[G24_SMEM_FLOATS];
-  const int M = a.m_ptr ? *a.m_ptr : a.M;
-  const int nby = (M + 127) >> 7, nbx = (a.N + 127) >> 7;
-  int bx, by, slab;
-  if (!tile_of_workgroup(nby * nbx * (int)gridDim.z, nbx, nby, bx, by, slab)) return;
-  g4_body<128>(a, M, bx, by, slab, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -751,12 +700,12 @@ int launch_gemm(ttx_session* s, hipStream_t st, const float* X, int ldx, const f
     hipLaunchKernelGGL(k_gemm3, dim3(cdiv(N, 32), cdiv(Mmax, 32), 1), dim3(256), 0, st, a);
   } else if (a.slice_k == 0) {
     hipLaunchKernelGGL((k_gemm_tn<2, 2>), dim3(cdiv(N, 64), cdiv(Mmax, 64), S), dim3(256), 0, st, a);
-  } else if (a.k_per_split % 256 == 0 && variant == GV_WIDE && (N >= 2048 || K >= 2048) && N % 128 == 0) {
-    // FFN1 / FFN2 of a step with many thousands of live rows (or of a bulk pass): 128x128 tiles, one workgroup per CU
-    hipLaunchKernelGGL(k_gemm_wide, dim3(cdiv(N, 128), cdiv(Mmax, 128), S), dim3(256), 0, st, a);
   } else if (a.k_per_split % 256 == 0 && !(step && variant == GV_SMALL)) {
-    // one launch that picks the tiling (128x64 / 64x64) from the live row count
-    a.big_min_tiles = s->big_min_tiles;
+    // one launch that picks the tiling (128x64 / 64x64) from the live row count.  Where the 128-row tiling starts to pay
+    // depends on how long a tile runs (profiles/r03_gemm_bench_canonical_slices.txt): deep contractions (FFN2, K = 2048) from
+    // about a third of the base count on, the 2048-wide FFN1 only from about twice the base count
+    a.big_min_tiles = K >= 2048 ? std::max(1, s->big_min_tiles / 3) : (N >= 2048 ? 2 * s->big_min_tiles : s->big_min_tiles);
+    if (s->big_min_tiles == 0) a.big_min_tiles = 0;
     dim3 grid(cdiv(N, 64), cdiv(Mmax, 64), S);
     if (a.k_per_split == 256) hipLaunchKernelGGL((k_gemm24<4>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_gemm24<0>), grid, dim3(256), 0, st, a);
@@ -796,9 +745,8 @@ int launch_finish(ttx_session* s, hipStream_t st, const float* slabs, int n_slab
 }
 
 // Development aid (tools/bench_gemm.py, ttx_debug_gemm_bench): one GEMM shape in isolation on random operands.
-// variant: 2 = 64x64 tiles (k_gemm24 with the 128-row tiling off), 46 = 128x64 tiles, 4 = 128x128 tiles (k_gemm_wide; N
-// a multiple of 128 and N or K >= 2048), 24 = k_gemm24's own choice, 3 = the one-wave-per-slice 32x32 kernel (K = 256),
-// 8 = one workgroup per slice (raw slabs).  `splits` > 0 asks for that many raw slabs.  Reports microseconds per launch over `reps` back-to-back launches
+// variant: 2 = 64x64 tiles (k_gemm24 with the 128-row tiling off), 46 = 128x64 tiles, 24 = k_gemm24's own choice,
+// 3 = the one-wave-per-slice 32x32 kernel (K = 256), 8 = one workgroup per slice (raw slabs).  `splits` > 0 asks for that many raw slabs.  Reports microseconds per launch over `reps` back-to-back launches
 // and the largest absolute difference of the (slab-summed, in slab order) result to the 64x64 tiling's.
 int gemm_bench(ttx_session* s, int M, int N, int K, int splits, int variant, int reps, double* us_per_launch, double* max_abs_diff) {
   if (!s || M <= 0 || N <= 0 || K <= 0 || gemm_slice_k(K) == 0 || reps <= 0) return fail(TTX_ERR_INVALID, "bad argument to ttx_debug_gemm_bench");
@@ -835,7 +783,6 @@ int gemm_bench(ttx_session* s, int M, int N, int K, int splits, int variant, int
     s->big_min_tiles = keep_min;
     if (var == 2) s->big_min_tiles = 0;
     else if (var == 46) s->big_min_tiles = 1;
-    else if (var == 4) gv = GV_WIDE;
     else if (var == 3 || var == 8) gv = GV_SMALL;
     return launch_gemm(s, st, dx, K, dw, K, n_slabs > 0 ? nullptr : db, y, N, dm, M, N, K, false, n_slabs, (long long)M * N, gv);
   };

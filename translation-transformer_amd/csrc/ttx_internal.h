@@ -48,10 +48,9 @@ struct Buf {
 // accumulated from zero in k order (ttx_gemm.hip), and both variants evaluate exactly that sum — so the choice is free
 // to follow the live row count of a step (it is made per step on the host) without touching a single bit of the result.
 //   GV_BIG    one workgroup walks all slices of its output tile (128x64 / 64x64 tiles by live row count)
-//   GV_WIDE   GV_BIG with 128x128 tiles (one workgroup per CU) for FFN1 / FFN2: steps with many thousands of live rows
 //   GV_SMALL  short dependent chains for steps of a few hundred rows: one wave per slice (32x32 tiles) for the K = 256
 //             GEMMs up to 768 columns, one workgroup per slice (split-K slabs, summed in order by k_finish_ln) for FFN2
-enum GemmVariant { GV_BIG = 0, GV_SMALL = 1, GV_WIDE = 2 };
+enum GemmVariant { GV_BIG = 0, GV_SMALL = 1 };
 
 struct GraphKey {
   int B, Ls, N, D, max_len, mode, kcap, variant;   // mode: 0 speculative, 1 plain greedy, 2 per-row rule, 3 slot pool
@@ -112,8 +111,7 @@ struct ttx_session {
   bool attr_attn2[8] = {false, false, false, false, false, false, false, false};
   bool attr_select = false, attr_step = false, attr_topk = false, attr_pool_select = false;
   // GEMM policy (all choices are between bit-identical evaluations, see GemmVariant)
-  int small_rows = 2560;           // a verify step with fewer live rows than this runs under GV_SMALL (TTX_SMALL_ROWS),
-  int wide_rows = 6144;            // one with at least this many under GV_WIDE (TTX_WIDE_ROWS)
+  int small_rows = 2560;           // a verify step with fewer live rows than this runs under GV_SMALL (TTX_SMALL_ROWS)
   // k_gemm24 picks the tiling per launch from the live row count: 128x64 tiles once there are big_min_tiles of them,
   // else 64x64 (TTX_BIG_MIN_TILES)
   int big_min_tiles = 400;
