@@ -698,8 +698,11 @@ __device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int 
 }
 
 constexpr int A3_QT = 32;            // step rows per wave
+#ifndef TTX_A3_WAVES
+#define TTX_A3_WAVES 2
+#endif
 template <int MODE, bool SPLIT>
-__global__ __launch_bounds__(256) void k_attn3(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TTX_A3_WAVES, TTX_A3_WAVES))) void k_attn3(AttnArgs a) {
   static_assert(MODE == ATT_STEP_SELF || MODE == ATT_STEP_CROSS, "k_attn3 serves the verify step");
   extern __shared__ __attribute__((aligned(16))) float a3_lds[];      // SPLIT: one A3_PART per key tile
   const int slot = blockIdx.x;

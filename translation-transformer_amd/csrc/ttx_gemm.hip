@@ -172,6 +172,33 @@ __device__ __forceinline__ void fold_slice(f32x16& tot, f32x16& acc, bool first)
   }
 }
 
+// The fold without a bubble in the matrix pipe: consecutive slices ALTERNATE between two accumulator sets.  A slice starts
+// with an MFMA whose C operand is the constant 0 (no register zeroing), and while its MFMAs run the finished slice in the other
+// set is added to the total with plain VALU adds (mode 1: the total IS that slice; 2: total += slice; 0: nothing to fold yet).
+// Same additions in the same order as fold_slice.
+__device__ __forceinline__ void fold_values(f32x16& tot, const f32x16& y, int mode, int lo, int hi) {
+  if (mode == 0) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i >= lo && i < hi) tot[i] = (mode == 1) ? y[i] : tot[i] + y[i];
+}
+
+// One 64-deep tile = one canonical slice into the fresh accumulator `x`, folding `y` meanwhile.
+template <int BK, int LDT>
+__device__ __forceinline__ void g2_mma_slice(f32x16& x, const f32x16& y, f32x16& tot, int mode, const float* ap, const float* bp) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < BK; kk += 8) {
+    const float4 av = *reinterpret_cast<const float4*>(ap + kk);
+    const float4 bv = *reinterpret_cast<const float4*>(bp + kk);
+    x = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, kk == 0 ? zero : x, 0, 0, 0);
+    x = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, x, 0, 0, 0);
+    x = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, x, 0, 0, 0);
+    x = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, x, 0, 0, 0);
+    if (kk == 0) fold_values(tot, y, mode, 0, 16);
+  }
+}
+
 constexpr int G24_SMEM_FLOATS = 2 * 2 * 64 * 68;       // 69 632 B: the larger of the two tilings' LDS images (64x64: two buffers of A and B, 64 x 68 each; 128x64: 2 x (128 + 64) x 36)
 
 // NT = number of 64-deep K tiles per workgroup when it is 1, 2 or 4 (straight-line code, every tile
@@ -223,6 +250,11 @@ __device__ __forceinline__ void g2_body(const GemmArgs& a, const int M, const in
     ++done;
     if (sliced && done % tiles_per_slice == 0) fold_slice(tot, acc, done == tiles_per_slice);
   };
+  // every tile its own slice (the K = d contractions): slices alternate between `acc` and `alt` (g2_mma_slice)
+  const bool per_tile = NT != 0 && sliced && tiles_per_slice == 1;     // (the open-ended ring keeps the plain fold: registers)
+  f32x16 alt;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) alt[i] = 0.f;
 
   if constexpr (NT == 1) {
     const G2Frag f0 = g2_load(p, 0);
@@ -235,8 +267,40 @@ __device__ __forceinline__ void g2_body(const GemmArgs& a, const int M, const in
     g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
     g2_store<LDT>(f1, As[1], Bs[1], lr, lc);
     __syncthreads();
-    tile_mma(As[0] + aoff, Bs[0] + boff);
-    tile_mma(As[1] + aoff, Bs[1] + boff);
+    if (per_tile) {
+      g2_mma_slice<BK, LDT>(acc, alt, tot, 0, As[0] + aoff, Bs[0] + boff);
+      g2_mma_slice<BK, LDT>(alt, acc, tot, 1, As[1] + aoff, Bs[1] + boff);
+      fold_values(tot, alt, 2, 0, 16);
+    } else {
+      tile_mma(As[0] + aoff, Bs[0] + boff);
+      tile_mma(As[1] + aoff, Bs[1] + boff);
+    }
+  } else if (per_tile) {
+    // the same ring with the four tiles of a pass going to acc, alt, acc, alt
+    G2Frag f0 = g2_load(p, 0);
+    G2Frag f1 = g2_load(p, BK);
+    G2Frag f2 = g2_load(p, 2 * BK);
+    G2Frag f3 = g2_load(p, 3 * BK);
+    const int last = ntiles - 1;
+    for (int base = 0; base < ntiles; base += RING) {
+      g2_store<LDT>(f0, As[0], Bs[0], lr, lc);
+      if constexpr (NT == 0) f0 = g2_load(p, min(base + RING, last) * BK);
+      __syncthreads();
+      g2_mma_slice<BK, LDT>(acc, alt, tot, base == 0 ? 0 : 2, As[0] + aoff, Bs[0] + boff);
+      g2_store<LDT>(f1, As[1], Bs[1], lr, lc);
+      if constexpr (NT == 0) f1 = g2_load(p, min(base + RING + 1, last) * BK);
+      __syncthreads();
+      g2_mma_slice<BK, LDT>(alt, acc, tot, base == 0 ? 1 : 2, As[1] + aoff, Bs[1] + boff);
+      g2_store<LDT>(f2, As[0], Bs[0], lr, lc);
+      if constexpr (NT == 0) f2 = g2_load(p, min(base + RING + 2, last) * BK);
+      __syncthreads();
+      g2_mma_slice<BK, LDT>(acc, alt, tot, 2, As[0] + aoff, Bs[0] + boff);
+      g2_store<LDT>(f3, As[1], Bs[1], lr, lc);
+      if constexpr (NT == 0) f3 = g2_load(p, min(base + RING + 3, last) * BK);
+      __syncthreads();
+      g2_mma_slice<BK, LDT>(alt, acc, tot, 2, As[1] + aoff, Bs[1] + boff);
+    }
+    fold_values(tot, alt, 2, 0, 16);
   } else {
     // ring of four register tiles, two LDS buffers; slot indices are compile-time (no register moves:
     // moving a pending load's destination would force a wait on it)
@@ -291,7 +355,7 @@ __device__ __forceinline__ void g2_body(const GemmArgs& a, const int M, const in
 }
 
 template <int NT>
-__global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm2(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 64 * 68];
   const int M = a.m_ptr ? *a.m_ptr : a.M;
   g2_body<NT>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
@@ -311,6 +375,7 @@ __global__ __launch_bounds__(256) void k_gemm2(GemmArgs a) {
 // slice_k / 64 pairs.
 struct G4Frag { float4 a0, a1, a2, a3, b0, b1; };
 
+template <bool ALT>
 __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const int bx, const int by, const int bz, float* smem) {
   constexpr int BM = 128, BN = 64, BK = 32, LDT = BK + 4;
   constexpr int WN = BN / 2;                      // columns per wave
@@ -357,16 +422,18 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
     *reinterpret_cast<float4*>(bs + 32 * LDT) = f.b1;
   };
 
-  f32x16 c00, c10;                // the running slice
-  f32x16 t00, t10;                // the folded total of the finished slices
+  // Two accumulator sets (a0x / a1x: even / odd slices) and the folded total.  A slice starts with MFMAs whose C operand is the
+  // constant 0; while it runs, the slice finished in the other set is folded into the total between the MFMAs (fold_values).
+  f32x16 a00, a10, b00, b10, t00, t10;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c10[i] = 0.f; t00[i] = 0.f; t10[i] = 0.f; }
+  for (int i = 0; i < 16; ++i) { a00[i] = 0.f; a10[i] = 0.f; b00[i] = 0.f; b10[i] = 0.f; t00[i] = 0.f; t10[i] = 0.f; }
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int aoff = (wm * 64 + r) * LDT + 4 * h, boff = (wn * WN + r) * LDT + 4 * h;
 
-  // One 32-deep K tile: 8 MFMAs per 8 k's.  `during(q)` (q = 0..3) runs after the first MFMA pair of every 8-k step: the
-  // LDS writes of the NEXT tile go there, between MFMAs, so that they cost no MFMA time (the matrix pipe runs on while the
-  // wave issues them).
-  auto mma = [&](int buf, auto&& during) {
+  // One 32-deep K tile into the accumulators (x0, x1): 8 MFMAs per 8 k's.  `fresh`: the tile opens a slice (C = 0 for its
+  // first MFMA pair).  `during(q)` (q = 0..3) runs after the first MFMA pair of every 8-k step: the LDS writes of the NEXT
+  // tile and a quarter of the pending fold go there, between MFMAs, so that they cost no MFMA time.
+  auto mma = [&](f32x16& x0, f32x16& x1, int buf, bool fresh, auto&& during) {
     const float* ap = As[buf] + aoff;
     const float* bp = Bs[buf] + boff;
     // fragments of the 8-k step after the current one are read from LDS while the current step's MFMAs run
@@ -381,15 +448,20 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
         na1 = *reinterpret_cast<const float4*>(ap + 32 * LDT + kk + 8);
         nb0 = *reinterpret_cast<const float4*>(bp + kk + 8);
       }
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c00, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, c10, 0, 0, 0);
+      if (kk == 0 && fresh) {                             // uniform branch: two straight-line versions of the first pair
+        x0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, zero, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, zero, 0, 0, 0);
+      } else {
+        x0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, x1, 0, 0, 0);
+      }
       during(kk >> 3);
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c00, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, c10, 0, 0, 0);
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c00, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, c10, 0, 0, 0);
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c00, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, c10, 0, 0, 0);
+      x0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, x1, 0, 0, 0);
+      x0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, x1, 0, 0, 0);
+      x0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, x1, 0, 0, 0);
       a0 = na0; a1 = na1; b0 = nb0;
     }
   };
@@ -409,9 +481,8 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
   // the bias value is requested before the K loop (a load still pending in the epilogue would make every predicated store
   // wait for vmcnt(0), i.e. for the previous store: 32 serialised round trips)
   const float bias0 = (!a.raw && a.bias) ? a.bias[min(bcol, a.N - 1)] : 0.f;
-  const int pairs_per_slice = a.slice_k > 0 ? a.slice_k / (2 * BK) : 0;
-  const bool sliced = pairs_per_slice > 0 && 2 * pairs_per_slice < ntiles;
-  int pairs = 0;
+  const int pairs_per_slice = (a.slice_k > 0 && a.slice_k < kend - kbeg) ? a.slice_k / (2 * BK) : ntiles / 2;   // not sliced: one slice
+  const int n_slices = (ntiles / 2) / pairs_per_slice;
   asm volatile("" ::: "memory");
   G4Frag f0 = gload(0);
   asm volatile("" ::: "memory");        // issue order f0 then f1 also ahead of the loop: the header waits with a counted vmcnt, not 0
@@ -424,23 +495,50 @@ __device__ __forceinline__ void g4_body(const GemmArgs& a, const int M, const in
   asm volatile("" ::: "memory");
   f0 = gload(min(2, last));
   __syncthreads();
-  for (int i = 0; i < ntiles; i += 2) {
-    mma(0, [&](int q) { lstore_q(f1, 1, q); });
-    asm volatile("" ::: "memory");
-    f1 = gload(min(i + 3, last));
-    __syncthreads();
-    mma(1, [&](int q) { lstore_q(f0, 0, q); });          // tile i + 2 (a clamped repeat of the last tile at the end: never read)
-    asm volatile("" ::: "memory");
-    f0 = gload(min(i + 4, last));
-    ++pairs;
-    if (sliced && pairs % pairs_per_slice == 0) {         // a canonical slice is complete: total += slice, fresh accumulators
-      const bool first = pairs == pairs_per_slice;
-      fold_slice(t00, c00, first);
-      fold_slice(t10, c10, first);
+  int i = 0;                                            // next tile
+  // one canonical slice into (x0, x1); the slice in (y0, y1) is folded into the total during its first tile (mode: fold_values)
+  auto slice = [&](f32x16& x0, f32x16& x1, const f32x16& y0, const f32x16& y1, int mode) {
+    for (int pr = 0; pr < pairs_per_slice; ++pr) {
+      const int m0f = pr == 0 ? mode : 0;
+      mma(x0, x1, 0, pr == 0, [&](int q) { lstore_q(f1, 1, q); fold_values(t00, y0, m0f, 4 * q, 4 * q + 4); fold_values(t10, y1, m0f, 4 * q, 4 * q + 4); });
+      asm volatile("" ::: "memory");
+      f1 = gload(min(i + 3, last));
+      __syncthreads();
+      mma(x0, x1, 1, false, [&](int q) { lstore_q(f0, 0, q); });      // tile i + 2 (a clamped repeat of the last tile at the end: never read)
+      asm volatile("" ::: "memory");
+      f0 = gload(min(i + 4, last));
+      __syncthreads();
+      i += 2;
     }
-    __syncthreads();
+  };
+  int s = 0;
+  if constexpr (ALT) {
+    for (; s + 1 < n_slices; s += 2) {
+      slice(a00, a10, b00, b10, s == 0 ? 0 : 2);
+      slice(b00, b10, a00, a10, s == 0 ? 1 : 2);
+    }
   }
-  if (sliced) { c00 = t00; c10 = t10; }
+  f32x16 c00, c10;
+  if constexpr (!ALT) {
+    // long slices (K >= 2048: eight 32-deep tiles each): the fold is rare, one accumulator set and a plain fold between slices
+    // leave more registers to the loads in flight
+    for (; s < n_slices; ++s) {
+      slice(a00, a10, b00, b10, 0);
+      fold_values(t00, a00, s == 0 ? 1 : 2, 0, 16); fold_values(t10, a10, s == 0 ? 1 : 2, 0, 16);
+    }
+    c00 = t00; c10 = t10;
+  } else if (n_slices == 1) {                                  // one chain over the whole range (raw slab of one slice, or no slicing)
+    slice(a00, a10, b00, b10, 0);
+    c00 = a00; c10 = a10;
+  } else {
+    if (s < n_slices) {                                 // odd count: the last slice goes to the first set
+      slice(a00, a10, b00, b10, 2);
+      fold_values(t00, a00, 2, 0, 16); fold_values(t10, a10, 2, 0, 16);
+    } else {
+      fold_values(t00, b00, 2, 0, 16); fold_values(t10, b10, 2, 0, 16);
+    }
+    c00 = t00; c10 = t10;
+  }
 
   float* Y = a.Y + (a.raw ? (size_t)bz * a.slab_stride : 0);
   const float lo = a.relu ? 0.f : -INFINITY;
@@ -487,7 +585,7 @@ __device__ __forceinline__ bool tile_of_workgroup(int n_tiles, int nbx, int nby,
 // tiling at least `big_min_tiles` workgroups, the first workgroups in dispatch order each compute such a tile and the others
 // leave at once, otherwise all compute their 64x64 tile.  Both evaluate the canonical slice sum: bit-identical results.
 template <int NT>
-__global__ __launch_bounds__(256) void k_gemm24(GemmArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm24(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[G24_SMEM_FLOATS];
   const int M = a.m_ptr ? *a.m_ptr : a.M;
   const int nby = (M + 127) >> 7, nbx = (a.N + 63) >> 6;
@@ -495,7 +593,7 @@ __global__ __launch_bounds__(256) void k_gemm24(GemmArgs a) {
   if (a.big_min_tiles > 0 && mid_tiles >= a.big_min_tiles) {
     int bx, by, slab;
     if (!tile_of_workgroup(mid_tiles, nbx, nby, bx, by, slab)) return;
-    g4_body(a, M, bx, by, slab, smem);
+    g4_body<NT == 4>(a, M, bx, by, slab, smem);
   } else {
     g2_body<NT>(a, M, blockIdx.x, blockIdx.y, blockIdx.z, smem);
   }
