@@ -1,5 +1,6 @@
 """pytest configuration: registers the ``gpu`` marker and puts the repo root on sys.path."""
 import sys
+import time
 from pathlib import Path
 
 import pytest
@@ -38,6 +39,7 @@ def trained_full_state():
         crit = torch.nn.CrossEntropyLoss()
         s, t = src.cuda(), tgt.cuda()
         model.train()
+        t0 = time.time()
         for step in range(900):
             loss = crit(model(s, t[:, :-1]).reshape(-1, V), t[:, 1:].reshape(-1))
             opt.zero_grad()
@@ -45,7 +47,7 @@ def trained_full_state():
             opt.step()
             if loss.item() < 5e-3:
                 break
-        print(f"full-size {n_layers}+{n_layers} fixture model: steps", step, "loss", loss.item())
+        print(f"full-size {n_layers}+{n_layers} fixture model: steps", step, "loss", loss.item(), f"({time.time() - t0:.1f} s)")
         assert loss.item() < 0.05
         cache[n_layers] = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
         return cache[n_layers]

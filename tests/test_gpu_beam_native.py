@@ -4,6 +4,7 @@ config C4 (d=256, 8 heads, FFN 2048, 6+6 layers; bs=8, n_best=10, n_drafts=2, dr
 configs/cfg_standard_single_step_retrosyn.yaml:96-103, scripts/single_step_retrosynthesis.sh:166-174) and C3 (4+4; bs=4,
 n_best=5, n_drafts=7, draft_len=10), against oracle.spec_beam on weights trained in the test."""
 import json
+import time
 
 import numpy as np
 import pytest
@@ -105,7 +106,7 @@ def _hyp_logprob(oracle, src_row, hyp):
     return float(lp[torch.arange(len(toks) - 1), t[0, 1:]].sum())
 
 
-def _compare_with_oracle(tta, native, oracle, sel, params, label):
+def _compare_with_oracle(tta, native, oracle, sel, params, label, modes=(False, True)):
     """HIP vs oracle.spec_beam on one batch.  Top-1 of every source must be identical.  A lower rank may only differ where
     the oracle itself scores the two hypotheses within 2e-3 of each other (the HIP and CPU forwards agree to ~1e-5 per logit,
     so two cumulative fp32 scores closer than that can rank either way): every difference is printed with both scores."""
@@ -113,11 +114,14 @@ def _compare_with_oracle(tta, native, oracle, sel, params, label):
     nbest, D, N, max_len = params
     _, _, c, V = fixture_tokens()
     n_diff = n_total = 0
-    for smart in (False, True):
+    for smart in modes:
         ref = BeamSearchSpeculativeOracle(oracle, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=400)
+        t0 = time.time()
         exp = ref.generate(sel).numpy()
+        t1 = time.time()
         g = tta.TranslationInferenceBeamSearchSpeculative(native, max_len, nbest, D, N, V, smart, PAD, BOS, EOS, c, max_steps=400)
         out = g.generate(sel.cuda()).cpu().numpy()
+        print(f"{label} smart={smart}: CPU oracle {t1 - t0:.1f} s, HIP path {time.time() - t1:.2f} s (first call: graph capture included)")
         assert out.shape[:2] == exp.shape[:2]
         exact = True
         for b in range(out.shape[0]):
@@ -142,7 +146,8 @@ def _compare_with_oracle(tta, native, oracle, sel, params, label):
 
 def test_config_c4_full_size_matches_oracle(tta, trained_full_state):
     """BASELINE config C4 at its real sizes: 6+6 layers of d=256 / 8 heads / FFN 2048, beam-speculative n_best 10, bs 8,
-    n_drafts 2, draft_len 10, max_len 200, both draft modes."""
+    n_drafts 2, draft_len 10, max_len 200: the full batch of 8 sources in the mode the bench times (all drafts) and a batch of 4
+    in smart-drafts mode (the CPU oracle takes about 8 s per source and mode)."""
     from oracle.model import OracleTransformer, config_from_state
     st = trained_full_state(6)
     native = tta.NativeTransformer(st, 8, 0, device=0)
@@ -152,8 +157,12 @@ def test_config_c4_full_size_matches_oracle(tta, trained_full_state):
     rows = [0, 2, 3, 4, 5, 6, 8, 9]
     sel = src[rows]
     sel = sel[:, :int((sel != PAD).sum(1).max())]
-    n_diff, n_total = _compare_with_oracle(tta, native, oracle, sel, (10, 10, 2, 200), "C4")
-    assert n_total == 2 * 8 * 10      # a differing lower rank only passes _compare_with_oracle as a proven near-tie (2e-3); none occurs
+    n_diff, n_total = _compare_with_oracle(tta, native, oracle, sel, (10, 10, 2, 200), "C4", modes=(False,))
+    sel4 = src[[0, 3, 5, 8]]
+    sel4 = sel4[:, :int((sel4 != PAD).sum(1).max())]
+    d4, t4 = _compare_with_oracle(tta, native, oracle, sel4, (10, 10, 2, 200), "C4 (4 sources)", modes=(True,))
+    n_diff, n_total = n_diff + d4, n_total + t4
+    assert n_total == (8 + 4) * 10    # a differing lower rank only passes _compare_with_oracle as a proven near-tie (2e-3)
     print("C4: hypotheses differing at a proven near-tie:", n_diff)
 
 
@@ -244,7 +253,7 @@ def test_standard_beam_search_small_cases_match_oracle(tta):
 
 
 def test_randomised_settings_match_oracle(tta):
-    """Forty random (rows, n_best, n_drafts, draft_len, max_len, draft mode) settings on the tiny model: every hypothesis and
+    """Twenty-eight random (rows, n_best, n_drafts, draft_len, max_len, draft mode) settings on the tiny model: every hypothesis and
     the counters equal the oracle's; where the oracle's loop does not terminate within the guard, neither does the native one."""
     from oracle.model import OracleTransformer, config_from_state
     from oracle.spec_beam import BeamSearchSpeculativeOracle
@@ -254,7 +263,7 @@ def test_randomised_settings_match_oracle(tta):
     src, _, c, V = fixture_tokens()
     rng = np.random.default_rng(20251004)
     compared = guarded = 0
-    for trial in range(40):
+    for trial in range(28):
         rows = rng.choice(10, size=int(rng.integers(1, 6)), replace=False).tolist()
         nbest = int(rng.choice([1, 2, 3, 5, 8]))
         N = int(rng.choice([1, 2, 3, 7, 23]))
@@ -280,7 +289,7 @@ def test_randomised_settings_match_oracle(tta):
                (ref.model_calls_num, ref.accepted_tokens_num, ref.produced_non_pad_tokens), label
         compared += 1
     print(f"randomised beam-speculative settings: {compared} compared, {guarded} hit the max_steps guard on both sides")
-    assert compared >= 25
+    assert compared >= 18
 
 
 def test_randomised_standard_beam_search_matches_oracle(tta):
@@ -291,7 +300,7 @@ def test_randomised_standard_beam_search_matches_oracle(tta):
     oracle = OracleTransformer(config_from_state(st, cfg["num_heads"]), st)
     src, _, _, _ = fixture_tokens()
     rng = np.random.default_rng(7)
-    for trial in range(16):
+    for trial in range(10):
         rows = rng.choice(10, size=int(rng.integers(1, 7)), replace=False).tolist()
         beam = int(rng.choice([1, 2, 3, 5, 10, 20]))
         max_len = int(rng.choice([3, 12, 60, 150]))

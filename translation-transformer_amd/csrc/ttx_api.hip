@@ -123,6 +123,10 @@ static int model_alloc(const ttx_config* cfg, int device, ttx_model** out) {
   ttx_model* m = new ttx_model();
   m->cfg = *cfg;
   m->device = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->n_cu = prop.multiProcessorCount;
+  }
   int r = build_layout(m);
   if (r != TTX_OK) { delete m; return r; }
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&m->blob, m->blob_floats * sizeof(float)) != hipSuccess) {
@@ -224,6 +228,38 @@ static void release_retired() {
   for (void* p : v) (void)hipFree(p);
 }
 
+// Session streams come from a per-device cache that outlives the sessions.  The runtime binds a stream to one of its few
+// hardware queues when the stream is created, round-robin over every stream the process ever made: the streams of a SECOND
+// model's sessions (after the first model was closed) landed two to a queue and its pools ran 7 % slower than in a fresh process
+// (tools/exp/inline_order.py, profiles/r03_stream_reuse.txt).  Handing the same streams out again, lowest creation index first,
+// gives every later set of sessions the queue layout of the first.
+static std::mutex g_stream_mu;
+static std::map<int, std::vector<std::pair<int, hipStream_t>>> g_free_streams;      // device -> (creation index, stream), idle
+static std::map<hipStream_t, int> g_stream_index;
+static int g_streams_made = 0;
+
+static int ensure_own_stream(ttx_session* s) {
+  if (s->own_stream) return TTX_OK;
+  std::lock_guard<std::mutex> lock(g_stream_mu);
+  auto& idle = g_free_streams[s->m->device];
+  if (!idle.empty()) {
+    auto it = std::min_element(idle.begin(), idle.end());
+    s->own_stream = it->second;
+    idle.erase(it);
+    return TTX_OK;
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  g_stream_index[s->own_stream] = g_streams_made++;
+  return TTX_OK;
+}
+
+static void release_own_stream(ttx_session* s) {        // the stream is idle (the caller synchronised the device)
+  if (!s->own_stream) return;
+  std::lock_guard<std::mutex> lock(g_stream_mu);
+  g_free_streams[s->m->device].push_back({g_stream_index[s->own_stream], s->own_stream});
+  s->own_stream = nullptr;
+}
+
 static int ensure(Buf& b, size_t bytes, hipStream_t st) {
   (void)st;
   if (bytes <= b.cap) return TTX_OK;
@@ -295,7 +331,7 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
   if (s->beam_host) (void)hipHostFree(s->beam_host);
   if (s->bp_host) (void)hipHostFree(s->bp_host);
   s->drop_graphs();
-  if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+  release_own_stream(s);
   if (s->ev_done) (void)hipEventDestroy(s->ev_done);
   if (s->host_state) (void)hipHostFree(s->host_state);
   for (auto& e : s->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -926,7 +962,7 @@ static int generate_common(ttx_session* s, const int64_t* d_src, int B, int Ls, 
   // The loop runs on the session's own stream (the caller's may be the legacy null stream, which cannot be
   // captured into a graph); it first waits for the caller's stream, and the call returns only after the
   // session stream has drained, so the outputs are visible to whatever the caller enqueues next.
-  if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  TTX_TRY(ensure_own_stream(s));
   HIP_TRY(hipEventRecord(s->ev_done, (hipStream_t)stream));
   HIP_TRY(hipStreamWaitEvent(s->own_stream, s->ev_done, 0));
   hipStream_t st = s->own_stream;
@@ -1161,7 +1197,7 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
   int rc_final = TTX_OK;
   for (int i = 0; i < n_jobs && rc_final == TTX_OK; ++i) {
     ttx_session* s = sessions[i];
-    if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    TTX_TRY(ensure_own_stream(s));
     HIP_TRY(hipStreamWaitEvent(s->own_stream, ready, 0));
     rc_final = pool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, d_out, d_traj, d_fin_step);
   }
@@ -1280,7 +1316,7 @@ static int generate_many_impl(ttx_session** sessions, int n_sessions, int n_batc
   bool hung = false;
   std::vector<GenJob> jobs(n_sessions);
   for (int i = 0; i < n_sessions; ++i) {
-    if (!sessions[i]->own_stream) HIP_TRY(hipStreamCreateWithFlags(&sessions[i]->own_stream, hipStreamNonBlocking));
+    TTX_TRY(ensure_own_stream(sessions[i]));
     HIP_TRY(hipStreamWaitEvent(sessions[i]->own_stream, ready, 0));
   }
   const int D1 = p->draft_len + 1;
@@ -1760,7 +1796,7 @@ extern "C" int ttx_beam_speculative_generate_many(ttx_session** sessions, int n_
   HIP_TRY(hipEventRecord(ready.e, (hipStream_t)stream));
   const int n_jobs = std::min(n_sessions, n_batches);
   for (int i = 0; i < n_jobs; ++i) {
-    if (!sessions[i]->own_stream) HIP_TRY(hipStreamCreateWithFlags(&sessions[i]->own_stream, hipStreamNonBlocking));
+    TTX_TRY(ensure_own_stream(sessions[i]));
     HIP_TRY(hipStreamWaitEvent(sessions[i]->own_stream, ready.e, 0));
   }
   std::vector<BeamJob> jobs(n_jobs);
@@ -2134,7 +2170,7 @@ extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_
   int rc_final = TTX_OK;
   for (int i = 0; i < n_jobs && rc_final == TTX_OK; ++i) {
     ttx_session* s = sessions[i];
-    if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    TTX_TRY(ensure_own_stream(s));
     HIP_TRY(hipStreamWaitEvent(s->own_stream, ready.e, 0));
     rc_final = bpool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, io, h_len, h_batch_of, h_given_ls, R_total, n_batches);
   }
@@ -2254,7 +2290,7 @@ extern "C" int ttx_beam_generate(ttx_session* s, const int64_t* d_src, int B, in
   if (max_len + 2 > c.max_positions) return fail(TTX_ERR_INVALID, "max_len exceeds the positional table");
   HIP_TRY(hipSetDevice(m->device));
   release_retired();
-  if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  TTX_TRY(ensure_own_stream(s));
   HIP_TRY(hipEventRecord(s->ev_done, (hipStream_t)stream));
   HIP_TRY(hipStreamWaitEvent(s->own_stream, s->ev_done, 0));
   hipStream_t st = s->own_stream;

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention v3 for the verify step: ONE WAVE per (running sequence, head, 32 step rows), no LDS, no barrier.
+// Attention v3 for the verify step: ONE WAVE per (running sequence, head, 32 step rows), no barrier in the main loop.
 //
 // Everything stays in the layout the fp32 MFMA produces.  Scores are computed TRANSPOSED, S^T = K Q^T (A operand =
 // 32 keys of the tile, B operand = the 32 queries), so a lane (r, h) ends up with 16 scores of ONE query r (keys
@@ -509,24 +509,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // the MFMA contracts; its A operand V^T is 16 coalesced 128-B row reads per tile.  O^T again keeps one query per
 // lane, so rescaling by exp(m_old - m_new) and the final 1/l are per-lane scalars.  Keys are visited in tiles of
 // 32 in a fixed order: a row's arithmetic does not depend on the batch it sits in.
+//
+// Arithmetic (the same whichever wave computes a tile): every 32-key tile i yields a partial (m_i, l_i, O_i) with its
+// own maximum; the partials are folded IN TILE ORDER into (M, L, O) by  M' = max(M, m_i),  L' = L e^(M-M') + l_i e^(m_i-M'),
+// O' likewise.  Two kernels evaluate it:
+//   k_attn3s  many sequences (row groups, slot pools): one wave per unit (sequence, head, 32 step rows), folding as it goes,
+//             the units of a launch STREAMED through a grid of the machine's size (see the kernel);
+//   k_attn3   few sequences (a 32-row batch): the four waves of a workgroup take tiles w, w+4, ... of ONE unit, park the
+//             partials in LDS and then fold them in tile order (wave w finishing dims 8w + 4h .. +3): bit-identical results,
+//             four times the parallelism.  The host picks by launch size.
+constexpr int A3_QT = 32;            // step rows per wave
+
 // A3Tile = what one 32-key tile needs from memory, per lane.
 struct A3Tile {
   float4 k0, k1, k2, k3;     // A operand of S^T: key key0 + r, dims 8g + 4h .. +3
   float v[16];               // A operand of O^T: V[key(t, h)][r], key(t, h) = key0 + (t&3) + 8(t>>2) + 4h
-  int own;                   // validity word of key key0 + r (token / source-valid byte), balloted below
+  int own;                   // validity word of key key0 + r (token / source-valid byte)
 };
 
-// `n_plain` = number of leading keys that every query sees whenever they are real tokens (cached prefix and front
-// token, or all encoder positions): tiles made of such keys skip the per-key flag arithmetic altogether.
-// `lin_limit`, `klin`, `vlin`, `lin_ld`: keys below lin_limit sit at klin/vlin + key * lin_ld (the cache, or the encoder
-// memory): a tile made of such keys takes its addresses from one base instead of sixteen per-key selections.
-//
-// Arithmetic (the same whichever wave computes a tile): every 32-key tile i yields a partial (m_i, l_i, O_i) with its
-// own maximum; the partials are folded IN TILE ORDER into (M, L, O) by  M' = max(M, m_i),  L' = L e^(M-M') + l_i e^(m_i-M'),
-// O' likewise.  SPLIT = false: one wave does all tiles of its (sequence, head) and folds as it goes.  SPLIT = true: the four
-// waves of a workgroup take tiles w, w+4, ... of ONE (sequence, head), park the partials in LDS and then fold them in
-// tile order (wave w finishing dims 8w + 4h .. +3): bit-identical results, four times the parallelism — used when few
-// sequences are decoded (a 32-row batch), chosen by the host from the launch size.
 __device__ __forceinline__ void a3_fold(float& M, float& L, float mi, float li, float& a, float& b) {
   const float Mn = fmaxf(M, mi);
   a = (M == -INFINITY) ? 0.f : __expf(M - Mn);
@@ -536,238 +536,365 @@ __device__ __forceinline__ void a3_fold(float& M, float& L, float mi, float li, 
 }
 constexpr int A3_PART = 16 * 64 + 64;          // floats of one parked tile partial: O_i [16][64], m_i [32], l_i [32]
 
-template <int MODE, bool SPLIT, typename KeyPtr, typename KeyOwn, typename KeyFlag, typename QFlag>
-__device__ __forceinline__ void attn3_core(const float* q, int ldq, int nq, int nk, int n_plain, int lin_limit, const float* klin,
-                                           const float* vlin, int lin_ld, KeyPtr keyptr, KeyOwn keyown, KeyFlag keyflag,
-                                           QFlag qflag, float* out, int ldo, float scale, float* lds) {
+// The scalars of one unit.  Keys of STEP_SELF: cached prefix [0, f) | step row 0 (position f) | the rows of every draft that has
+// a query in this unit's 32 rows.  Keys below `lin_limit` sit at klin / vlin + key * lin_ld (the cache, or the encoder memory): a
+// tile made of such keys takes its addresses from one base.  `n_plain` = number of leading keys that every query sees whenever
+// they are real tokens (cached prefix and front token, or all encoder positions): tiles made of such keys skip the per-key
+// visibility flags altogether.
+struct A3Unit {
+  const float* q; float* out;
+  const float* klin; const float* vlin;
+  const float* kb; const float* vb;            // STEP_SELF: this step's K / V rows of the sequence (packed QKV buffer)
+  const int* tk;                               // STEP_SELF: the sequence's token row
+  const uint8_t* kvalid;                       // STEP_CROSS: source-valid bytes
+  int nq, nk, n_plain, lin_limit, ntiles;
+  int f, kr0, n_lo, r0;
+};
+
+__device__ __forceinline__ int a3_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// x / D for 0 <= x < 2^32 / D without a division per lane: magic = floor(2^32 / D) + 1 (D >= 2)
+__device__ __forceinline__ unsigned a3_magic(int D) { return D >= 2 ? (unsigned)(0x100000000ull / (unsigned)D) + 1u : 0u; }
+__device__ __forceinline__ int a3_div(int x, int D, unsigned magic) { return D >= 2 ? (int)__umulhi((unsigned)x, magic) : x; }
+
+template <int MODE>
+__device__ __forceinline__ A3Unit a3_unit(const AttnArgs& a, int slot, int head, int qt, int RPS, unsigned magic) {
+  A3Unit c;
+  const int hd = head * ATT_DH;
+  const int r0 = qt * A3_QT;
+  const int b = a3_uniform(a.act_idx[slot]);
+  const size_t srow0 = (size_t)slot * RPS;
+  c.r0 = r0;
+  c.nq = min(A3_QT, RPS - r0);
+  c.q = a.q + (srow0 + r0) * a.ldq + hd;
+  c.out = a.out + (srow0 + r0) * a.d + hd;
+  if constexpr (MODE == ATT_STEP_SELF) {
+    const int D = a.D;
+    const int f = a3_uniform(a.front[b]);
+    const int rlast = r0 + c.nq - 1;
+    const int n_lo = (r0 == 0) ? 0 : a3_div(r0 - 1, D, magic);
+    const int n_hi = (rlast == 0) ? -1 : a3_div(rlast - 1, D, magic);
+    const int n_draft_keys = (n_hi >= n_lo && D > 0) ? (n_hi - n_lo + 1) * D : 0;
+    c.f = f;
+    c.n_lo = n_lo;
+    c.kr0 = 1 + n_lo * D;
+    c.tk = a.tok + (size_t)b * a.gen_ld;
+    c.klin = a.kcache + (size_t)b * a.cache_seq_stride + hd;
+    c.vlin = a.vcache + (size_t)b * a.cache_seq_stride + hd;
+    c.kb = a.k + srow0 * a.ldkv + hd;
+    c.vb = a.v + srow0 * a.ldkv + hd;
+    c.kvalid = nullptr;
+    c.nk = f + 1 + n_draft_keys;
+    c.n_plain = f + 1;
+    c.lin_limit = f;
+  } else {
+    const size_t mrow0 = (size_t)(a.src_of ? a3_uniform(a.src_of[b]) : b) * a.Lk;
+    const int nkeys = a.src_len ? a3_uniform(a.src_len[b]) : a.Lk;      // see k_attn: slot pool
+    c.kvalid = a.key_pad + mrow0;
+    c.klin = a.k + mrow0 * a.ldkv + hd;
+    c.vlin = a.v + mrow0 * a.ldkv + hd;
+    c.kb = c.klin;
+    c.vb = c.vlin;
+    c.tk = nullptr;
+    c.f = 0; c.kr0 = 0; c.n_lo = 0;
+    c.nk = nkeys;
+    c.n_plain = (nkeys + 31) & ~31;
+    c.lin_limit = nkeys;
+  }
+  c.ntiles = (c.nk + 31) >> 5;
+  return c;
+}
+
+// K / V row of key `key` (0 <= key < nk) as an offset in floats from the unit's bases: 32-bit arithmetic (a sequence's cache, its
+// step rows and a source's memory rows each span far less than 2^31 floats)
+template <int MODE>
+__device__ __forceinline__ void a3_keyrow(const AttnArgs& a, const A3Unit& c, int key, const float*& kp, const float*& vp) {
+  if constexpr (MODE == ATT_STEP_SELF) {
+    const bool cached = key < c.f;
+    const int srow = (key == c.f) ? 0 : c.kr0 + (key - c.f - 1);
+    const int off = cached ? key * a.d : srow * a.ldkv;
+    kp = (cached ? c.klin : c.kb) + off;
+    vp = (cached ? c.vlin : c.vb) + off;
+  } else {
+    const int off = key * a.ldkv;
+    kp = c.klin + off;
+    vp = c.vlin + off;
+  }
+}
+template <int MODE>
+__device__ __forceinline__ int a3_keyown(const AttnArgs& a, const A3Unit& c, int key) {
+  if constexpr (MODE == ATT_STEP_SELF) return c.tk[min(key, c.f)] != a.pad ? 1 : 0;      // prefix / front token is a real token
+  else return (int)c.kvalid[key];
+}
+// visibility flag of key `key` (a2_visible's convention); `real` = the key's validity word; keys past nk are masked
+template <int MODE>
+__device__ __forceinline__ int a3_keyflag(const AttnArgs& a, const A3Unit& c, int key, bool real, unsigned magic) {
+  if (key >= c.nk) return A2_MASKED;
+  if constexpr (MODE == ATT_STEP_SELF) {
+    const int D = a.D;
+    const int kr = c.kr0 + max(key - c.f - 1, 0);
+    const int kn = a3_div(kr - 1, max(D, 1), magic);
+    const int draft_flag = a2_flag(kn - c.n_lo, kr - 1 - kn * D);
+    return key <= c.f ? (real ? A2_ALL : A2_MASKED) : draft_flag;
+  } else {
+    return real ? A2_ALL : A2_MASKED;
+  }
+}
+template <int MODE>
+__device__ __forceinline__ int a3_qflag(const AttnArgs& a, const A3Unit& c, int qi, unsigned magic) {
+  if constexpr (MODE == ATT_STEP_SELF) {
+    const int D = a.D;
+    const int qr = c.r0 + qi;
+    if (qr == 0 || D == 0) return a2_flag(0x3fff, 0);           // sees prefix + front token only
+    const int qn = a3_div(qr - 1, D, magic);
+    return a2_flag(qn - c.n_lo, qr - 1 - qn * D);
+  } else {
+    return 0;
+  }
+}
+
+struct A3Query {
+  float qx[16];              // B operand of S^T: query r, dims 8g + 4h .. +3, already times the scale
+  int qf;                    // (rows past nq repeat the last query; they are never stored)
+};
+
+template <int MODE>
+__device__ __forceinline__ A3Query a3_load_query(const AttnArgs& a, const A3Unit& c, int r, int h, unsigned magic) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  // B operand of S^T: query r, dims 8g + 4h .. +3 (rows past nq repeat the last query; they are never stored)
-  f32x4 qv[4];
-  {
-    const float* qp = q + (size_t)min(r, nq - 1) * ldq + 4 * h;
+  A3Query qq;
+  const float* qp = c.q + (size_t)min(r, c.nq - 1) * a.ldq + 4 * h;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      qv[g] = *reinterpret_cast<const f32x4*>(qp + 8 * g);
-      qv[g] *= scale;
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(qp + 8 * g);
+    v *= a.scale;
+    qq.qx[4 * g] = v.x; qq.qx[4 * g + 1] = v.y; qq.qx[4 * g + 2] = v.z; qq.qx[4 * g + 3] = v.w;
+  }
+  qq.qf = a3_qflag<MODE>(a, c, min(r, c.nq - 1), magic);
+  return qq;
+}
+
+// every load of a tile is unconditional (key indices clamped to nk - 1; such keys are masked): a conditional load
+// costs a branch and a full vmcnt(0) round trip each
+template <int MODE>
+__device__ __forceinline__ A3Tile a3_load_tile(const AttnArgs& a, const A3Unit& c, int key0, int r, int h) {
+  A3Tile tl;
+  const int lin_ld = (MODE == ATT_STEP_SELF) ? a.d : a.ldkv;
+  if (key0 + 32 <= c.lin_limit) {                   // uniform: all 32 keys exist and are laid out linearly
+    const float* kp = c.klin + (key0 + r) * lin_ld + 4 * h;
+    tl.k0 = *reinterpret_cast<const float4*>(kp);
+    tl.k1 = *reinterpret_cast<const float4*>(kp + 8);
+    tl.k2 = *reinterpret_cast<const float4*>(kp + 16);
+    tl.k3 = *reinterpret_cast<const float4*>(kp + 24);
+    tl.own = a3_keyown<MODE>(a, c, key0 + r);
+    const float* vp = c.vlin + (key0 + 4 * h) * lin_ld + r;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) tl.v[t] = vp[((t & 3) + 8 * (t >> 2)) * lin_ld];
+    return tl;
+  }
+  const float *kp, *vp;
+  const int kown = min(key0 + r, c.nk - 1);
+  a3_keyrow<MODE>(a, c, kown, kp, vp);
+  tl.k0 = *reinterpret_cast<const float4*>(kp + 4 * h);
+  tl.k1 = *reinterpret_cast<const float4*>(kp + 4 * h + 8);
+  tl.k2 = *reinterpret_cast<const float4*>(kp + 4 * h + 16);
+  tl.k3 = *reinterpret_cast<const float4*>(kp + 4 * h + 24);
+  tl.own = a3_keyown<MODE>(a, c, kown);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const float *kq, *vq;
+    a3_keyrow<MODE>(a, c, min(key0 + (t & 3) + 8 * (t >> 2) + 4 * h, c.nk - 1), kq, vq);
+    tl.v[t] = vq[r];
+  }
+  return tl;
+}
+
+// One tile's partial (m_i = mx, l_i = rs, O_i = oi) from its loaded operands.
+template <int MODE>
+__device__ __forceinline__ void a3_tile_partial(const AttnArgs& a, const A3Unit& c, const A3Tile& cur, const A3Query& q, int key0,
+                                                int r, int h, unsigned magic, float& mx, float& rs, f32x16& oi) {
+  f32x16 sacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.x, q.qx[0], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.y, q.qx[1], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.z, q.qx[2], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.w, q.qx[3], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.x, q.qx[4], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.y, q.qx[5], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.z, q.qx[6], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.w, q.qx[7], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.x, q.qx[8], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.y, q.qx[9], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.z, q.qx[10], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.w, q.qx[11], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.x, q.qx[12], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.y, q.qx[13], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.z, q.qx[14], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.w, q.qx[15], sacc, 0, 0, 0);
+  mx = -INFINITY;
+  if (key0 + 32 <= c.n_plain) {                       // uniform: a tile of plain keys (most tiles)
+    // validity of the tile's 32 keys as a bit mask (lanes 0..31 hold keys key0 .. key0+31), keys past nk cleared
+    unsigned valid = (unsigned)__ballot(cur.own != 0);
+    if (c.nk - key0 < 32) valid &= (1u << (c.nk - key0)) - 1u;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int j = (t & 3) + 8 * (t >> 2) + 4 * h;
+      sacc[t] = ((valid >> j) & 1u) ? sacc[t] : -INFINITY;
+      mx = fmaxf(mx, sacc[t]);
+    }
+  } else {
+    // the flag of key key0 + r is worked out ONCE, by the lane that loaded the key (one magic-number division per lane and
+    // tile), and handed to the lanes that hold its scores: key (t&3) + 8(t>>2) + 4h sits in lane (t&3) + 8(t>>2) (+ 4)
+    const int kflag = a3_keyflag<MODE>(a, c, key0 + r, cur.own != 0, magic);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int j0 = (t & 3) + 8 * (t >> 2);
+      const int kf0 = __builtin_amdgcn_readlane(kflag, j0), kf1 = __builtin_amdgcn_readlane(kflag, j0 + 4);
+      const bool vis = a2_visible(q.qf, h ? kf1 : kf0);
+      sacc[t] = vis ? sacc[t] : -INFINITY;
+      mx = fmaxf(mx, sacc[t]);
     }
   }
-  const int qf = qflag(min(r, nq - 1));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));                               // m_i
+  const float base = (mx == -INFINITY) ? 0.f : mx;                  // nothing visible in this tile: every exp below is 0
+  rs = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    sacc[t] = __expf(sacc[t] - base);
+    rs += sacc[t];
+  }
+  rs += __shfl_xor(rs, 32);                                          // l_i
+#pragma unroll
+  for (int i = 0; i < 16; ++i) oi[i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) oi = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[t], sacc[t], oi, 0, 0, 0);
+}
+
+// Few sequences: one workgroup per unit, its key tiles shared out over the four waves.
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attn3(AttnArgs a) {
+  static_assert(MODE == ATT_STEP_SELF || MODE == ATT_STEP_CROSS, "k_attn3 serves the verify step");
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float a3_lds[];      // one A3_PART per key tile
+  const int slot = blockIdx.x;
+  if (slot >= a.st->n_active) return;
+  const int RPS = step_rps(a.N, a.D);
+  if ((int)blockIdx.z * A3_QT >= RPS) return;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const unsigned magic = a3_magic(a.D);
+  const A3Unit c = a3_unit<MODE>(a, slot, blockIdx.y, blockIdx.z, RPS, magic);
+  const A3Query q = a3_load_query<MODE>(a, c, r, h, magic);
+  A3Tile cur = a3_load_tile<MODE>(a, c, min(wave, c.ntiles - 1) * 32, r, h);
+  for (int it = wave; it < c.ntiles; it += 4) {
+    // the next tile's loads go out before this tile's arithmetic (the empty asm keeps them above it); the copy at the
+    // bottom of the loop is where they are waited for
+    A3Tile nxt = a3_load_tile<MODE>(a, c, min(it + 4, c.ntiles - 1) * 32, r, h);
+    asm volatile("" ::: "memory");
+    float mx, rs;
+    f32x16 oi;
+    a3_tile_partial<MODE>(a, c, cur, q, it * 32, r, h, magic, mx, rs, oi);
+    float* part = a3_lds + (size_t)it * A3_PART;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[i * 64 + lane] = oi[i];
+    if (h == 0) { part[16 * 64 + r] = mx; part[16 * 64 + 32 + r] = rs; }
+    cur = nxt;
+  }
+  __syncthreads();
+  float m = -INFINITY, l = 0.f;
+  float o4[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < c.ntiles; ++it) {            // the fold, in tile order; this wave owns values 4w .. 4w+3
+    const float* part = a3_lds + (size_t)it * A3_PART;
+    float fa, fb;
+    a3_fold(m, l, part[16 * 64 + r], part[16 * 64 + 32 + r], fa, fb);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) o4[v] = __fmaf_rn(o4[v], fa, __fmul_rn(part[(4 * wave + v) * 64 + lane], fb));
+  }
+  if (r < c.nq) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    f32x4 w = {o4[0] * inv, o4[1] * inv, o4[2] * inv, o4[3] * inv};
+    *reinterpret_cast<f32x4*>(c.out + (size_t)r * a.d + 4 * h + 8 * wave) = w;
+  }
+}
+
+// Many sequences: the units of the launch as a STREAM.  A pool launch reads ~8 KB of K/V per tile and head, and a wave that
+// handled one unit and exited would spend its first tile's memory latency (and the dependent scalar loads in front of it:
+// slot -> sequence -> front / source) idle, in phase with every other wave that started with it.  Here the grid has the
+// machine's size (two waves per SIMD) and every wave walks units u = wave, wave + W, ...: while the last tile of a unit is in the
+// matrix pipe, the first tile and the queries of the NEXT unit are already in flight, and that unit's scalars were fetched one
+// unit earlier.
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attn3s(AttnArgs a, int H, int qtiles) {
+  static_assert(MODE == ATT_STEP_SELF || MODE == ATT_STEP_CROSS, "k_attn3s serves the verify step");
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int RPS = step_rps(a.N, a.D);
+  const unsigned magic = a3_magic(a.D);
+  const int W = (int)gridDim.x * 4;
+  const int n_units = a.st->n_active * H * qtiles;
+  int u = a3_uniform((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (u >= n_units) return;
+  // unit u = ((slot * qtiles) + q tile) * H + head
+  auto unit = [&](int uu) {
+    const int head = uu % H, t = uu / H;
+    return a3_unit<MODE>(a, t / qtiles, head, t % qtiles, RPS, magic);
+  };
+  A3Unit cu = unit(u);
+  A3Query cq = a3_load_query<MODE>(a, cu, r, h, magic);
+  A3Tile cur = a3_load_tile<MODE>(a, cu, 0, r, h);
+  int un = u + W;
+  A3Unit nu = unit(min(un, n_units - 1));               // the next unit's scalars, one unit ahead
   float m = -INFINITY, l = 0.f;
   f32x16 o;
 #pragma unroll
   for (int i = 0; i < 16; ++i) o[i] = 0.f;
-
-  // every load of a tile is unconditional (key indices clamped to nk - 1; such keys are masked): a conditional load
-  // costs a branch and a full vmcnt(0) round trip each
-  auto load_tile = [&](int key0) {
-    A3Tile tl;
-    if (key0 + 32 <= lin_limit) {                   // uniform: all 32 keys exist and are laid out linearly
-      const float* kp = klin + (size_t)(key0 + r) * lin_ld + 4 * h;
-      tl.k0 = *reinterpret_cast<const float4*>(kp);
-      tl.k1 = *reinterpret_cast<const float4*>(kp + 8);
-      tl.k2 = *reinterpret_cast<const float4*>(kp + 16);
-      tl.k3 = *reinterpret_cast<const float4*>(kp + 24);
-      tl.own = keyown(key0 + r);
-      const float* vp = vlin + (size_t)(key0 + 4 * h) * lin_ld + r;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) tl.v[t] = vp[(size_t)((t & 3) + 8 * (t >> 2)) * lin_ld];
-      return tl;
+  int it = 0;
+  for (;;) {
+    const bool last = it + 1 >= cu.ntiles;
+    const bool more = un < n_units;
+    // what the matrix pipe needs next goes out before this tile's arithmetic: the unit's next tile, or the first tile and the
+    // queries of the next unit
+    A3Tile nxt = cur;
+    A3Query nq = cq;
+    if (!last) {
+      nxt = a3_load_tile<MODE>(a, cu, it * 32 + 32, r, h);
+    } else if (more) {
+      nxt = a3_load_tile<MODE>(a, nu, 0, r, h);
+      nq = a3_load_query<MODE>(a, nu, r, h, magic);
     }
-    const float *kp, *vp;
-    const int kown = min(key0 + r, nk - 1);
-    keyptr(kown, kp, vp);
-    tl.k0 = *reinterpret_cast<const float4*>(kp + 4 * h);
-    tl.k1 = *reinterpret_cast<const float4*>(kp + 4 * h + 8);
-    tl.k2 = *reinterpret_cast<const float4*>(kp + 4 * h + 16);
-    tl.k3 = *reinterpret_cast<const float4*>(kp + 4 * h + 24);
-    tl.own = keyown(kown);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const float *kq, *vq;
-      keyptr(min(key0 + (t & 3) + 8 * (t >> 2) + 4 * h, nk - 1), kq, vq);
-      tl.v[t] = vq[r];
-    }
-    return tl;
-  };
-
-  const int ntiles = (nk + 31) >> 5;
-  const int wave = SPLIT ? (int)(threadIdx.x >> 6) : 0;
-  constexpr int TSTEP = SPLIT ? 4 : 1;
-  A3Tile cur = load_tile(min(wave, ntiles - 1) * 32);
-  for (int it = wave; it < ntiles; it += TSTEP) {
-    const int key0 = it * 32;
-    // the next tile's loads go out before this tile's arithmetic (the empty asm keeps them above it); the copy at the
-    // bottom of the loop is where they are waited for
-    A3Tile nxt = load_tile(min(it + TSTEP, ntiles - 1) * 32);
     asm volatile("" ::: "memory");
-    f32x16 sacc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.x, qv[0].x, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.y, qv[0].y, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.z, qv[0].z, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k0.w, qv[0].w, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.x, qv[1].x, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.y, qv[1].y, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.z, qv[1].z, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k1.w, qv[1].w, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.x, qv[2].x, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.y, qv[2].y, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.z, qv[2].z, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k2.w, qv[2].w, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.x, qv[3].x, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.y, qv[3].y, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.z, qv[3].z, sacc, 0, 0, 0);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.k3.w, qv[3].w, sacc, 0, 0, 0);
-    // validity of the tile's 32 keys as a bit mask (lanes 0..31 hold keys key0 .. key0+31), keys past nk cleared
-    unsigned valid = (unsigned)__ballot(cur.own != 0);
-    if (nk - key0 < 32) valid &= (1u << (nk - key0)) - 1u;
-    float mx = -INFINITY;
-    if (key0 + 32 <= n_plain) {                       // uniform: a tile of plain keys (most tiles)
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int j = (t & 3) + 8 * (t >> 2) + 4 * h;
-        sacc[t] = ((valid >> j) & 1u) ? sacc[t] : -INFINITY;
-        mx = fmaxf(mx, sacc[t]);
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int j = (t & 3) + 8 * (t >> 2) + 4 * h;
-        const int kf = keyflag(min(key0 + j, nk - 1), (valid >> j) & 1u);     // keys past nk: valid bit 0 -> see below
-        const bool vis = (key0 + j < nk) && a2_visible(qf, kf);
-        sacc[t] = vis ? sacc[t] : -INFINITY;
-        mx = fmaxf(mx, sacc[t]);
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));                               // m_i
-    const float base = (mx == -INFINITY) ? 0.f : mx;                  // nothing visible in this tile: every exp below is 0
-    float rs = 0.f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      sacc[t] = __expf(sacc[t] - base);
-      rs += sacc[t];
-    }
-    rs += __shfl_xor(rs, 32);                                          // l_i
+    float mx, rs, fa, fb;
     f32x16 oi;
+    a3_tile_partial<MODE>(a, cu, cur, cq, it * 32, r, h, magic, mx, rs, oi);
+    a3_fold(m, l, mx, rs, fa, fb);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) oi[i] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) oi = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[t], sacc[t], oi, 0, 0, 0);
-    if constexpr (!SPLIT) {
-      float fa, fb;
-      a3_fold(m, l, mx, rs, fa, fb);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[i] = __fmaf_rn(o[i], fa, __fmul_rn(oi[i], fb));
-    } else {
-      float* part = lds + (size_t)it * A3_PART;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) part[i * 64 + lane] = oi[i];
-      if (h == 0) { part[16 * 64 + r] = mx; part[16 * 64 + 32 + r] = rs; }
-    }
+    for (int i = 0; i < 16; ++i) o[i] = __fmaf_rn(o[i], fa, __fmul_rn(oi[i], fb));
     cur = nxt;
-  }
-  if constexpr (SPLIT) {
-    __syncthreads();
-    float o4[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int it = 0; it < ntiles; ++it) {            // the same fold, in tile order; this wave owns values 4w .. 4w+3
-      const float* part = lds + (size_t)it * A3_PART;
-      float fa, fb;
-      a3_fold(m, l, part[16 * 64 + r], part[16 * 64 + 32 + r], fa, fb);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) o4[c] = __fmaf_rn(o4[c], fa, __fmul_rn(part[(4 * wave + c) * 64 + lane], fb));
+    if (!last) {
+      ++it;
+      continue;
     }
-    if (r < nq) {
+    // o[v] = O[query r][dim (v&3) + 8(v>>2) + 4h]: four float4 per lane
+    if (r < cu.nq) {
       const float inv = l > 0.f ? 1.0f / l : 0.f;
-      f32x4 w = {o4[0] * inv, o4[1] * inv, o4[2] * inv, o4[3] * inv};
-      *reinterpret_cast<f32x4*>(out + (size_t)r * ldo + 4 * h + 8 * wave) = w;
-    }
-    return;
-  }
-  // o[v] = O[query r][dim (v&3) + 8(v>>2) + 4h]: four float4 per lane
-  if (r < nq) {
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    float* op = out + (size_t)r * ldo + 4 * h;
+      float* op = cu.out + (size_t)r * a.d + 4 * h;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      f32x4 w = {o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv};
-      *reinterpret_cast<f32x4*>(op + 8 * c) = w;
+      for (int v = 0; v < 4; ++v) {
+        f32x4 w = {o[4 * v] * inv, o[4 * v + 1] * inv, o[4 * v + 2] * inv, o[4 * v + 3] * inv};
+        *reinterpret_cast<f32x4*>(op + 8 * v) = w;
+      }
     }
+    if (!more) break;
+    cu = nu;
+    cq = nq;
+    un += W;
+    nu = unit(min(un, n_units - 1));
+    it = 0;
+    m = -INFINITY;
+    l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
   }
 }
-
-constexpr int A3_QT = 32;            // step rows per wave
-#ifndef TTX_A3_WAVES
-#define TTX_A3_WAVES 2
-#endif
-template <int MODE, bool SPLIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TTX_A3_WAVES, TTX_A3_WAVES))) void k_attn3(AttnArgs a) {
-  static_assert(MODE == ATT_STEP_SELF || MODE == ATT_STEP_CROSS, "k_attn3 serves the verify step");
-  extern __shared__ __attribute__((aligned(16))) float a3_lds[];      // SPLIT: one A3_PART per key tile
-  const int slot = blockIdx.x;
-  if (slot >= a.st->n_active) return;
-  const int head = SPLIT ? (int)blockIdx.y : (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
-  const int hd = head * ATT_DH;
-  const int D = a.D, RPS = step_rps(a.N, a.D);
-  const int r0 = blockIdx.z * A3_QT;
-  const int nq = min(A3_QT, RPS - r0);
-  if (nq <= 0) return;
-  const int b = a.act_idx[slot];
-  const size_t srow0 = (size_t)slot * RPS;
-  if constexpr (MODE == ATT_STEP_SELF) {
-    const int f = a.front[b];
-    const int* tk = a.tok + (size_t)b * a.gen_ld;
-    const int pad = a.pad;
-    const float* kc = a.kcache + (size_t)b * a.cache_seq_stride + hd;
-    const float* vc = a.vcache + (size_t)b * a.cache_seq_stride + hd;
-    const float* kb = a.k + srow0 * a.ldkv + hd;
-    const float* vb = a.v + srow0 * a.ldkv + hd;
-    const int ld = a.ldkv, dd = a.d;
-    // keys: cached prefix [0,f) | step row 0 (position f) | the rows of every draft that has a query in this tile
-    const int rlast = r0 + nq - 1;
-    const int n_lo = (r0 == 0) ? 0 : (r0 - 1) / D;
-    const int n_hi = (rlast == 0) ? -1 : (rlast - 1) / D;
-    const int kr0 = 1 + n_lo * D;
-    const int n_draft_keys = (n_hi >= n_lo && D > 0) ? (n_hi - n_lo + 1) * D : 0;
-    attn3_core<MODE, SPLIT>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, f + 1 + n_draft_keys, f + 1, f, kc, vc, dd,
-                     [=](int key, const float*& kp, const float*& vp) {
-                       const bool cached = key < f;
-                       const int srow = (key == f) ? 0 : kr0 + (key - f - 1);
-                       const size_t off = cached ? (size_t)key * dd : (size_t)srow * ld;
-                       kp = (cached ? kc : kb) + off;
-                       vp = (cached ? vc : vb) + off;
-                     },
-                     [=](int key) { return tk[min(key, f)] != pad ? 1 : 0; },       // prefix / front token is a real token
-                     [=](int key, unsigned real) {
-                       const int kr = kr0 + max(key - f - 1, 0);
-                       const int kn = (kr - 1) / max(D, 1);
-                       const int draft_flag = a2_flag(kn - n_lo, kr - 1 - kn * D);
-                       return key <= f ? (real ? A2_ALL : A2_MASKED) : draft_flag;
-                     },
-                     [=](int qi) {
-                       const int qr = r0 + qi;
-                       if (qr == 0 || D == 0) return a2_flag(0x3fff, 0);
-                       const int qn = (qr - 1) / D;
-                       return a2_flag(qn - n_lo, qr - 1 - qn * D);
-                     },
-                     a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, a3_lds);
-  } else {
-    const size_t mrow0 = (size_t)(a.src_of ? a.src_of[b] : b) * a.Lk;
-    const uint8_t* kvalid = a.key_pad + mrow0;
-    const float* kb = a.k + mrow0 * a.ldkv + hd;
-    const float* vb = a.v + mrow0 * a.ldkv + hd;
-    const int ld = a.ldkv;
-    const int nkeys = a.src_len ? a.src_len[b] : a.Lk;
-    attn3_core<MODE, SPLIT>(a.q + (srow0 + r0) * a.ldq + hd, a.ldq, nq, nkeys, ((nkeys + 31) & ~31), nkeys, kb, vb, ld,
-                     [=](int key, const float*& kp, const float*& vp) { kp = kb + (size_t)key * ld; vp = vb + (size_t)key * ld; },
-                     [=](int key) { return (int)kvalid[key]; },
-                     [=](int, unsigned real) { return real ? A2_ALL : A2_MASKED; },
-                     [](int) { return 0; },
-                     a.out + (srow0 + r0) * a.d + hd, a.d, a.scale, a3_lds);
-  }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 static constexpr size_t kAttn2LdsLimit = 150 * 1024;
@@ -783,13 +910,20 @@ static int launch_attn_mode(ttx_session* s, hipStream_t st, const AttnArgs& a, i
     // the verify step: one wave per (sequence, head, 32 step rows), registers only — no key-count limit
     if (H % 4 == 0 && !s->attn_fallback) {
       // few sequences (a 32-row batch): the key tiles of one (sequence, head) are shared out over the four waves of
-      // a workgroup; many (row groups, slot pools): one wave per (sequence, head).  Bit-identical either way.
+      // a workgroup (k_attn3); many (row groups, slot pools): one wave per (sequence, head), streamed (k_attn3s).
+      // Bit-identical either way.
       const int qtiles = cdiv(q_per_group, A3_QT);
       const int keys3 = (MODE == ATT_STEP_SELF) ? max_keys + 1 + N * std::max(D, 0) : max_keys;
       const size_t lds3 = sizeof(float) * (size_t)A3_PART * cdiv(keys3, 32);
       const bool split = s->attn_split != 0 && (s->attn_split > 0 || (long long)groups * H * qtiles < 2048) && lds3 <= 64 * 1024;
-      if (split) hipLaunchKernelGGL((k_attn3<MODE, true>), dim3(groups, H, qtiles), dim3(256), lds3, st, a);
-      else hipLaunchKernelGGL((k_attn3<MODE, false>), dim3(groups, H / 4, qtiles), dim3(256), 0, st, a);
+      if (split) {
+        hipLaunchKernelGGL((k_attn3<MODE>), dim3(groups, H, qtiles), dim3(256), lds3, st, a);
+      } else {
+        // a grid of the machine's size (two workgroups = eight waves per CU), every wave walking its share of the units
+        const long long units = (long long)groups * H * qtiles;
+        const int wgs = (int)std::min<long long>((units + 3) / 4, 2LL * s->m->n_cu);
+        hipLaunchKernelGGL((k_attn3s<MODE>), dim3(wgs), dim3(256), 0, st, a, H, qtiles);
+      }
       HIP_TRY(hipGetLastError());
       return TTX_OK;
     }

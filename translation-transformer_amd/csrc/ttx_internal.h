@@ -28,6 +28,7 @@ struct LayerW {
 struct ttx_model {
   ttx_config cfg;
   int device;
+  int n_cu = 256;                  // compute units of the device (grids sized to the machine: k_attn3s)
   float* blob = nullptr;
   size_t blob_floats = 0;
   std::map<std::string, std::pair<size_t, size_t>> index;  // name -> (offset, numel)
