@@ -146,7 +146,7 @@ def work(cfg: dict, positions: int, src_tokens: int, steps: int, batches: int, k
     dec_io = 4 * (Ld * ((d + 3 * d) + 3 * (d + d) + (d + F) + (F + 2 * d)) + (d + V))
     enc_io = 4 * (Le * ((d + 3 * d) + (d + d) + (d + F) + (F + d)) + (d + Ld * 2 * d))
     gemm_bytes = positions * dec_io + src_tokens * enc_io + steps * W_dec + batches * (W_enc + 4 * Ld * 2 * d * d)
-    return {"gemm_flops": float(gemm_flops), "bytes": float(bytes_total), "gemm_bytes": float(gemm_bytes)}
+    return {"gemm_flops": float(gemm_flops), "bytes": float(bytes_total), "gemm_bytes": float(gemm_bytes), "steps": int(steps), "Ld": Ld}
 
 
 def pmc_traffic_for(key: dict):
@@ -231,6 +231,11 @@ def roofline_record(kernel: str, prof: dict, w_pass: dict, w_timed: dict, timed_
     timed region.  achieved = algorithmic GEMM FLOPs of the pass / sum of its per-launch event durations, each net of the
     bracketing overhead calibrated on the same stream; frac_wall = GEMM FLOPs of the timed region / its wall time / peak."""
     launches = max(1, prof["launches"])
+    # every session of the pass must have bracketed its launches: a verify step alone makes 6 GEMM launches per decoder layer + 1
+    least = int(w_pass.get("steps", 0)) * (6 * int(w_pass.get("Ld", 0)) + 1)
+    if prof["launches"] < least:
+        raise SystemExit(f"bench.py: the roofline pass bracketed {prof['launches']} GEMM launches but its {w_pass.get('steps')} verify steps "
+                         f"alone make {least}: some sessions of the pass did not profile")
     raw_ms = prof["gemm_ms"]
     net_ms = max(1e-9, raw_ms - launches * prof["pair_overhead_ms"])
     ach = w_pass["gemm_flops"] / (net_ms * 1e-3) / 1e12

@@ -1,6 +1,7 @@
-"""tools/roofline_from_trace.py on a small synthetic rocprofv3 trace: the roofline pass is found BY STREAM (the stream whose
-GEMM launch count equals bench.py's roofline.launches), its average launch duration and achieved TFLOP/s are recomputed from
-the trace, and the PMC passes are reduced to bytes per launch for exactly those launches."""
+"""tools/roofline_from_trace.py on a small synthetic rocprofv3 trace: the roofline pass is the LAST roofline.launches GEMM
+launches of the process (it runs on the timed region's own pools, i.e. on several streams; the same number of launches before it
+is its warm run), its average launch duration and achieved TFLOP/s are recomputed from the trace, and the PMC passes are reduced
+to bytes per launch for exactly those launches."""
 import csv
 import json
 import subprocess
@@ -35,14 +36,16 @@ def _counters(path, rows, counter, value):
             w.writerow({c: 0 for c in cols} | {"Dispatch_Id": i + 1, "Kernel_Name": name, "Counter_Name": counter, "Counter_Value": value})
 
 
-def test_roofline_pass_is_found_by_stream_and_reduced(tmp_path):
+def test_roofline_pass_is_the_last_launches_and_reduced(tmp_path):
     gemm = "void ttx::k_gemm24<4>(ttx::GemmArgs)"
     rows = []
-    for i in range(10):                                   # timed region: stream 2, 10 GEMM launches of 50 us
-        rows.append((2, gemm, 1000 * i, 50_000))
-    for i in range(6):                                    # roofline pass: stream 7, 6 GEMM launches of 20 us + other kernels
-        rows.append((7, gemm, 100_000 + 1000 * i, 20_000))
-        rows.append((7, "ttx::k_finish_ln<4>(ttx::FinishArgs)", 200_000 + 1000 * i, 5_000))
+    for i in range(10):                                   # timed region: 10 GEMM launches of 50 us on two streams
+        rows.append((2 + i % 2, gemm, 1000 * i, 50_000))
+    for i in range(6):                                    # warm run of the pass: same shapes, 30 us
+        rows.append((2 + i % 2, gemm, 100_000 + 1000 * i, 30_000))
+    for i in range(6):                                    # roofline pass: 6 GEMM launches of 20 us on two streams + other kernels
+        rows.append((2 + i % 2, gemm, 200_000 + 1000 * i, 20_000))
+        rows.append((2 + i % 2, "ttx::k_finish_ln<4>(ttx::FinishArgs)", 200_500 + 1000 * i, 5_000))
     _trace(tmp_path / "t.csv", rows)
     _counters(tmp_path / "f_cc.csv", rows, "FETCH_SIZE", 1000.0)      # KB per launch
     _counters(tmp_path / "w_cc.csv", rows, "WRITE_SIZE", 500.0)
@@ -56,7 +59,8 @@ def test_roofline_pass_is_found_by_stream_and_reduced(tmp_path):
                         str(tmp_path / "t.csv"), "--pmc-json", str(out_json), "--command", "test"],
                        input='{"schedule": "rows", "inflight": 8}', capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    assert "roofline pass = stream 7 (6 GEMM launches" in r.stdout
+    assert "roofline pass = the last 6 GEMM launches of the process on streams ['2', '3']" in r.stdout
+    assert "have the same (kernel, grid) counts" in r.stdout
     assert "average 20.00 us per launch" in r.stdout
     assert "100.0 TFLOP/s" in r.stdout                    # 6 x 2 GFLOP / 120 us
     entry = json.loads(out_json.read_text())[0]

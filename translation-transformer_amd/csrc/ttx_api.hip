@@ -301,10 +301,9 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   s->use_graphs = getenv("TTX_NO_GRAPH") == nullptr;
   const char* pf = getenv("TTX_PROFILE_GEMM");
   s->profile = pf && pf[0] == '1';
-  // experiments: where the host switches between the bit-identical GEMM variants / tilings
+  // tuning knob: the live row count below which a step takes the short-chain GEMM variant (identical bits)
   if (const char* e = getenv("TTX_SMALL_ROWS")) s->small_rows = std::max(0, atoi(e));
-  if (const char* e = getenv("TTX_BIG_MIN_TILES")) s->big_min_tiles = std::max(0, atoi(e));
-  if (const char* e = getenv("TTX_ATTN_SPLIT")) s->attn_split = atoi(e);
+  // test hook: every attention launch on the streaming fallback kernel
   if (const char* e = getenv("TTX_ATTN_FALLBACK")) s->attn_fallback = atoi(e) != 0;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
   *out = s;
@@ -1201,9 +1200,7 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
     HIP_TRY(hipStreamWaitEvent(s->own_stream, ready, 0));
     rc_final = pool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, d_out, d_traj, d_fin_step);
   }
-  int admit_div = 4;
-  if (const char* e = getenv("TTX_POOL_ADMIT_DIV")) admit_div = std::max(1, atoi(e));
-  const int min_admit = std::max(1, C / admit_div);
+  const int min_admit = std::max(1, C / 4);                    // admissions of at least a quarter pool (or into an empty one)
   int cursor = 0, done = 0;
   while (done < n_jobs && rc_final == TTX_OK) {
     bool progressed = false;
@@ -2174,9 +2171,7 @@ extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_
     HIP_TRY(hipStreamWaitEvent(s->own_stream, ready.e, 0));
     rc_final = bpool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, io, h_len, h_batch_of, h_given_ls, R_total, n_batches);
   }
-  int admit_div = 4;
-  if (const char* e = getenv("TTX_POOL_ADMIT_DIV")) admit_div = std::max(1, atoi(e));
-  const int min_admit = std::max(1, C / admit_div);
+  const int min_admit = std::max(1, C / 4);                    // admissions of at least a quarter pool (or into an empty one)
   int cursor_b = 0, done = 0;                                  // next batch of the work list
   const auto t_call = std::chrono::steady_clock::now();
   bool hung = false;

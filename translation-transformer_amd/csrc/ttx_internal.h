@@ -116,7 +116,7 @@ struct ttx_session {
   // k_gemm24 picks the tiling per launch from the live row count: 128x64 tiles once there are big_min_tiles of them,
   // else 64x64 (TTX_BIG_MIN_TILES)
   int big_min_tiles = 400;
-  int attn_split = -1;             // TTX_ATTN_SPLIT: -1 by launch size, 0 never, 1 always (key tiles of a head over 4 waves)
+  int attn_split = -1;             // -1 by launch size, 0 never, 1 always (key tiles of a head over 4 waves)
   bool attn_fallback = false;      // TTX_ATTN_FALLBACK=1 (test hook): every attention launch on the streaming kernel k_attn
   // profiling of the GEMM launches (bench.py roofline): a HIP event pair around every GEMM launch
   bool profile = false;

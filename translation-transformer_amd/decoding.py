@@ -107,7 +107,7 @@ class TranslationInferenceGreedySpeculative:
         if reorder:
             try:
                 if pool is None:
-                    pool = os.environ.get("TTX_ROW_POOL", "1") != "0"
+                    pool = True
                 return self._generate_reordered(batches, in_flight, group_size, on_error, pool)
             except N.TtxError as e:
                 if e.code != N.TTX_ERR_ROW_REPLAY:
@@ -149,8 +149,6 @@ class TranslationInferenceGreedySpeculative:
     def _generate_reordered(self, batches: list, in_flight: int, group_size: int | None, on_error: str = "raise",
                             pool: bool = True) -> list:
         from .scheduling import plan_row_groups, replay_batch
-        import time as _time
-        _t0 = _time.perf_counter()
         m = self.model
         L, T = self.max_len, self.max_len + 1
         srcs = [b.to(m.device, torch.int64) for b in batches]
@@ -212,7 +210,6 @@ class TranslationInferenceGreedySpeculative:
             stats = (N.GenStats * n)()
             N.check(m._lib.ttx_greedy_speculative_generate_rows(sess, len(sessions), n, src_p, Bs, Ls, C.byref(p), out_p, traj_p, fin_p,
                                                                 stats, m._stream()))
-        _t1 = _time.perf_counter()
         # back to the caller's row order, then the reference's per-batch loop over the traces
         inv = torch.empty_like(order_t)
         inv[order_t] = torch.arange(R, device=m.device)
@@ -260,11 +257,6 @@ class TranslationInferenceGreedySpeculative:
             raise N.ReferenceError_(f"batch {failed}: a row finished at a width beyond max_len: shape mismatch in the reference "
                                     "(speculative_decoding.py:158)")
         out_rows = torch.where(keep.to(m.device)[:, None], out_rows, torch.full_like(out_rows, self.pad_token))
-        if os.environ.get("TTX_HOST_PROFILE"):
-            torch.cuda.synchronize()
-            import sys as _sys
-            print(f"[ttx rows] prepare+device {1e3 * (_t1 - _t0):.1f} ms, replay+scatter {1e3 * (_time.perf_counter() - _t1):.1f} ms",
-                  file=_sys.stderr, flush=True)
         outs, r0 = [], 0
         skipped = set(self.last_failed_batches)
         for bi, B in enumerate(sizes):
@@ -435,7 +427,7 @@ class TranslationInferenceBeamSearchSpeculative:
         for b in srcs:
             m.check_tokens(b)
         if pool is None:
-            pool = len(srcs) > 1 and os.environ.get("TTX_BEAM_POOL", "1") != "0"
+            pool = len(srcs) > 1
         # smart mode needs a window library for every batch (Ls - 5 > 0, drafting.py:39); max_len < 3 never enters the loop
         d0 = self.draft_len if not self.smart_drafts_mode else min(max(5, self.draft_len + 1), 200) - 1
         if pool and self.max_len >= 3 and all(int(b.shape[1]) >= 2 and (not self.smart_drafts_mode or int(b.shape[1]) > 5) for b in srcs):

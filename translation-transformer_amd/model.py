@@ -10,6 +10,7 @@ the current stream only; every FLOP happens in libttx_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -76,6 +77,9 @@ class NativeTransformer:
         self._lib = N.lib()
         self._model = C.c_void_p()
         self._session = C.c_void_p()
+        # TTX_PROFILE_GEMM=1 at construction makes EVERY session of this model a profiling one (new_session below), not only the
+        # first: the slot pools' later sessions are created long after the caller dropped the variable again
+        self._profile_sessions = os.environ.get("TTX_PROFILE_GEMM") == "1"
         if st is None:
             N.check(self._lib.ttx_model_create_empty(C.byref(self.cfg), dev.index or 0, C.byref(self._model)))
             N.check(self._lib.ttx_session_create(self._model, C.byref(self._session)))
@@ -112,7 +116,17 @@ class NativeTransformer:
 
     def new_session(self) -> C.c_void_p:
         s = C.c_void_p()
-        N.check(self._lib.ttx_session_create(self._model, C.byref(s)))
+        had = os.environ.get("TTX_PROFILE_GEMM")
+        if self._profile_sessions:
+            os.environ["TTX_PROFILE_GEMM"] = "1"
+        try:
+            N.check(self._lib.ttx_session_create(self._model, C.byref(s)))
+        finally:
+            if self._profile_sessions:
+                if had is None:
+                    os.environ.pop("TTX_PROFILE_GEMM", None)
+                else:
+                    os.environ["TTX_PROFILE_GEMM"] = had
         return s
 
     def session_pool(self, n: int) -> list:
