@@ -2270,8 +2270,19 @@ extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_
 // ------------------------------------------------------------------------------------------------
 // Standard beam search, whole loop native (standard_decoding.py:89-174): per-hypothesis KV cache (the tree kernels),
 // the verify-step kernels with one row per running hypothesis, k_beam_step for log-softmax + top-beam + row assembly.
+static int beam_generate_impl(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_beam_search_params* p, int64_t* d_out,
+                              ttx_beam_search_stats* stats, void* stream);
+
 extern "C" int ttx_beam_generate(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_beam_search_params* p, int64_t* d_out,
                                  ttx_beam_search_stats* stats, void* stream) {
+  const int rc = beam_generate_impl(s, d_src, B, Ls, p, d_out, stats, stream);
+  // an error return must not leave work of this call in flight on the session's stream (the caller may free d_src / d_out)
+  if (rc != TTX_OK && s && !s->dead && s->own_stream) (void)hipStreamSynchronize(s->own_stream);
+  return rc;
+}
+
+static int beam_generate_impl(ttx_session* s, const int64_t* d_src, int B, int Ls, const ttx_beam_search_params* p, int64_t* d_out,
+                              ttx_beam_search_stats* stats, void* stream) {
   if (!s || !d_src || !p || !d_out || !stats || B <= 0 || Ls <= 1) return fail(TTX_ERR_INVALID, "bad argument to ttx_beam_generate");
   TTX_TRY(session_alive(s));
   const ttx_model* m = s->m;

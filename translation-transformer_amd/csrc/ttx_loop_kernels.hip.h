@@ -247,20 +247,23 @@ __global__ __launch_bounds__(ACCEPT_THREADS) void k_accept(LoopArgs a) {
     const int slot = base + threadIdx.x;
     const int code = slot < Bc ? a.rec[slot].b : -1;
     const int keep = (slot < Bc && a.rec[slot].flags == 0) ? 1 : 0;
-    s_scan[threadIdx.x] = keep;
+    // ordered compaction: position = kept slots of the earlier waves + kept lanes below this one (ballots, two barriers)
+    const unsigned long long mask = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_scan[wave] = __popcll(mask);
     __syncthreads();
-    for (int off = 1; off < blockDim.x; off <<= 1) {   // inclusive Hillis-Steele scan over <= 256 flags
-      const int v = (threadIdx.x >= off) ? s_scan[threadIdx.x - off] : 0;
-      __syncthreads();
-      s_scan[threadIdx.x] += v;
-      __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+      const int c = s_scan[w];
+      before += (w < wave) ? c : 0;
+      total += c;
     }
     if (keep) {
-      a.act_idx[nn_before + s_scan[threadIdx.x] - 1] = code;
+      a.act_idx[nn_before + before + __popcll(mask & ((1ull << lane) - 1ull))] = code;
       if (a.haspad[code]) s_suspect = 1;
       atomicMax(&s_maxf_new, a.front[code]);
     }
-    nn_before += s_scan[blockDim.x - 1];
+    nn_before += total;
     __syncthreads();
   }
   const int wout = a.row_rule ? a.max_len : wcopy;    // columns past a row's front are PAD either way
@@ -312,8 +315,7 @@ __global__ __launch_bounds__(ACCEPT_THREADS) void k_accept(LoopArgs a) {
     a.host->stop = stop;
     __threadfence_system();
     a.host->steps_done = st->steps;                  // last: the host reads the other words once it sees this one move
-    __threadfence_system();
-  }
+  }                                                  // (the kernel's end releases it; the graph's next node is far away)
 }
 
 // ------------------------------------------------------------------------------------------------
