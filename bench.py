@@ -561,7 +561,8 @@ def measure_c2(ctx: Ctx, a, tta) -> dict:
             "picked per launch from the live row count, one wave per slice for steps of few rows; every GEMM launch of the pass: "
             "encoder, cross K/V, verify steps)", prof, c2_work(pstats, len(timed)), w_timed, elapsed,
             "a further run of the timed region's own call (same slot pools, sessions and streams) right after it, on sessions that launch "
-            "eagerly and bracket every GEMM launch with a HIP event pair on its launch stream", pmc, pmc_why)
+            "eagerly and bracket every GEMM launch with a HIP event pair on its launch stream; the pools of this pass run one after "
+            "another (in the timed region they overlap), so that a pair times its own launch and not other pools' kernels", pmc, pmc_why)
         pm.close()
         log("profile pass done")
     if world == 1 and not a.no_cpu_baseline:
@@ -697,7 +698,8 @@ def measure_beam(ctx: Ctx, a, tta, name: str, steps: int, warmup: int, full: boo
             "k_gemm24<NT> / k_gemm2<NT> / k_gemm3 (fp32 v_mfma_f32_32x32x2_f32 GEMM family, canonical slice order) — every GEMM launch "
             "of the pass: encoders of the admitted batches, cross K/V, the pools' verify steps", prof, beam_work(pg), w_timed, elapsed,
             "a further run of the timed region's own call (same batch pools, sessions and streams) on sessions that launch eagerly and "
-            "bracket every GEMM launch with a HIP event pair on its launch stream", pmc, pmc_why,
+            "bracket every GEMM launch with a HIP event pair on its launch stream; the pools of this pass run one after another (in the "
+            "timed region they overlap), so that a pair times its own launch and not other pools' kernels", pmc, pmc_why,
             {"gemm_share_of_device_time": prof["gemm_ms"] / max(1e-9, pg.stats_total["encode_ms"] + pg.stats_total["decode_ms"])})
         pm.close()
     if world == 1 and not a.no_cpu_baseline:

@@ -1015,6 +1015,7 @@ struct PoolJob {
   int launched = 0;
   int phase = 0;            // 0 not started, 1 running, 2 finishing, 3 done
   int admits = 0;
+  int quota_end = -1;       // serial (profiling) pass: end of this pool's share of the work list
   PoolIo io{};
   unsigned idle_spins = 0;
   std::chrono::steady_clock::time_point last_progress = std::chrono::steady_clock::now();
@@ -1201,10 +1202,18 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
     rc_final = pool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, d_out, d_traj, d_fin_step);
   }
   const int min_admit = std::max(1, C / 4);                    // admissions of at least a quarter pool (or into an empty one)
+  const bool serial = sessions[0]->profile;
   int cursor = 0, done = 0;
   while (done < n_jobs && rc_final == TTX_OK) {
     bool progressed = false;
+    // profiling sessions (bench.py's roofline pass): the pools run ONE AFTER ANOTHER, so that the event pair around a GEMM launch
+    // measures that launch and not the kernels of three other pools sharing the device with it
+    int only = -1;
+    if (serial)
+      for (int i = n_jobs - 1; i >= 0; --i)
+        if (jobs[i].phase != 3) only = i;
     for (int i = 0; i < n_jobs && rc_final == TTX_OK; ++i) {
+      if (serial && i != only) continue;
       PoolJob& j = jobs[i];
       ttx_session* s = j.s;
       volatile HostInfo* hi = s->host_info;
@@ -1222,16 +1231,20 @@ extern "C" int ttx_greedy_speculative_generate_pool(ttx_session** sessions, int 
         j.last_progress = std::chrono::steady_clock::now();
         int n_act = (j.launched == 0) ? 0 : hi->n_active;
         const int free_slots = C - n_act;
-        if (cursor < R_total && (n_act == 0 || free_slots >= min_admit)) {
+        // serial pass: every pool decodes an equal contiguous share of the rest of the list (what it takes at once when the list
+        // fits the pools; otherwise its own continuous batching over that share, one tail per pool as in the concurrent run)
+        if (serial && j.quota_end < 0) j.quota_end = cursor + cdiv(R_total - cursor, n_jobs - i);
+        const int list_end = serial ? j.quota_end : R_total;
+        if (cursor < list_end && (n_act == 0 || free_slots >= min_admit)) {
           // the last rows of the list are shared out over the pools still running, so that they drain together
           // instead of one pool swallowing the rest and finishing alone
           int n_running = 0;
           for (const PoolJob& o : jobs) n_running += (o.phase == 1);
-          const int remaining = R_total - cursor;
-          int share = std::max(1, cdiv(remaining, std::max(1, n_running)));
+          const int remaining = list_end - cursor;
+          int share = std::max(1, cdiv(remaining, std::max(1, serial ? 1 : n_running)));
           // first fill of a list that fits the pools at once: an equal share for every pool not yet started (the pools
           // before this one have taken theirs), so that nothing is left waiting for a later admission
-          if (j.launched == 0 && (long long)n_jobs * C >= R_total) share = std::max(1, cdiv(remaining, n_jobs - i));
+          if (!serial && j.launched == 0 && (long long)n_jobs * C >= R_total) share = std::max(1, cdiv(remaining, n_jobs - i));
           const int take = std::min({free_slots, remaining, share});
           int Ls_new = 2;                                                      // longest row of the chunk
           for (int r = cursor; r < cursor + take; ++r) Ls_new = std::max(Ls_new, (int)h_len[r]);
@@ -1870,6 +1883,7 @@ struct BeamPoolJob {
   int launched = 0, cur = 0;
   int phase = 0;                    // 0 not started, 1 running, 2 finishing, 3 done
   int admitted_since = 0;           // sources admitted since the last published iteration
+  int quota_b = -1;                 // serial (profiling) pass: end (batch index) of this pool's share of the work list
   long long src_tokens_padded = 0, admitted_rows = 0;
   unsigned idle_spins = 0;
   std::chrono::steady_clock::time_point last_progress = std::chrono::steady_clock::now();
@@ -2172,13 +2186,19 @@ extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_
     rc_final = bpool_start(jobs[i], s, s->own_stream, C, Ls_cap, p, io, h_len, h_batch_of, h_given_ls, R_total, n_batches);
   }
   const int min_admit = std::max(1, C / 4);                    // admissions of at least a quarter pool (or into an empty one)
+  const bool serial = sessions[0]->profile;
   int cursor_b = 0, done = 0;                                  // next batch of the work list
   const auto t_call = std::chrono::steady_clock::now();
   bool hung = false;
   ttx_beam_stats acc{};
   while (done < n_jobs && rc_final == TTX_OK) {
     bool progressed = false;
+    int only = -1;                       // profiling sessions: one pool after another (see the greedy pool)
+    if (serial)
+      for (int i = n_jobs - 1; i >= 0; --i)
+        if (jobs[i].phase != 3) only = i;
     for (int i = 0; i < n_jobs && rc_final == TTX_OK; ++i) {
+      if (serial && i != only) continue;
       BeamPoolJob& j = jobs[i];
       ttx_session* s = j.s;
       volatile BeamPoolHost* bh = s->bp_host;
@@ -2191,16 +2211,22 @@ extern "C" int ttx_beam_speculative_generate_pool(ttx_session** sessions, int n_
         int n_live = (j.launched == 0 ? 0 : bh->n_live) + j.admitted_since;
         int n_running = (j.launched == 0 ? 0 : bh->n_running) + j.admitted_since;
         const int free_slots = C - n_live;
-        if (cursor_b < n_batches && (n_live == 0 || free_slots >= std::max(min_admit, first[cursor_b + 1] - first[cursor_b]))) {
+        if (serial && j.quota_b < 0) {                  // serial pass: an equal contiguous share of the rest of the list (greedy pool)
+          const int target = first[cursor_b] + cdiv(R_total - first[cursor_b], n_jobs - i);
+          j.quota_b = cursor_b;
+          while (j.quota_b < n_batches && first[j.quota_b] < target) ++j.quota_b;
+        }
+        const int list_end_b = serial ? j.quota_b : n_batches;
+        if (cursor_b < list_end_b && (n_live == 0 || free_slots >= std::max(min_admit, first[cursor_b + 1] - first[cursor_b]))) {
           // whole batches, as many as fit; the last batches of the list are shared out over the pools still running, so that
           // they drain together, and a first fill that fits the pools at once is split evenly
           int n_run_jobs = 0;
           for (const BeamPoolJob& o : jobs) n_run_jobs += (o.phase == 1);
-          const int remaining = R_total - first[cursor_b];
-          int share = std::max(1, cdiv(remaining, std::max(1, n_run_jobs)));
-          if (j.launched == 0 && (long long)n_jobs * C >= R_total) share = std::max(1, cdiv(remaining, n_jobs - i));
+          const int remaining = first[list_end_b] - first[cursor_b];
+          int share = std::max(1, cdiv(remaining, std::max(1, serial ? 1 : n_run_jobs)));
+          if (!serial && j.launched == 0 && (long long)n_jobs * C >= R_total) share = std::max(1, cdiv(remaining, n_jobs - i));
           int take = 0, b_end = cursor_b;
-          while (b_end < n_batches) {
+          while (b_end < list_end_b) {
             const int sz = first[b_end + 1] - first[b_end];
             if (take + sz > free_slots || (take > 0 && take + sz > share)) break;
             take += sz;
