@@ -275,3 +275,34 @@ def test_out_of_range_token_ids_raise_like_torch_embedding(tta, tiny):
     neg[0, 1] = -1
     with pytest.raises(IndexError):
         tta.TranslationInferenceGreedy(tiny, 150, PAD, BOS, EOS).generate(neg.cuda())
+
+
+def test_profiling_model_brackets_every_pool_session_and_changes_no_output(tta, tiny, monkeypatch):
+    """The model bench.py builds for its roofline pass (TTX_PROFILE_GEMM=1 at construction): EVERY pool session it creates
+    later brackets its GEMM launches (the count covers at least 6 launches per decoder layer + the classifier for every device
+    step of every pool), the pools run one after another, and the outputs are those of an ordinary model."""
+    fsrc, _, c, V = fixture_tokens()
+    src = fsrc.repeat(8, 1)[torch.randperm(80, generator=torch.Generator().manual_seed(3))]       # 80 rows -> three pools
+    batches = [src[i:i + 8] for i in range(0, 80, 8)]
+    batches = [b[:, :int((b != PAD).sum(1).max())].cuda() for b in batches]
+    g_ref = tta.TranslationInferenceGreedySpeculative(tiny, 150, 10, 3, PAD, BOS, EOS, c)
+    ref = g_ref.generate_many(batches, in_flight=4, reorder=True, group_size=32, on_error="skip")
+    assert "device" in g_ref.stats_total                     # the slot pools ran (no fallback to the batches as given)
+    st, cfg = tiny_state()
+    monkeypatch.setenv("TTX_PROFILE_GEMM", "1")
+    pm = tta.NativeTransformer(st, cfg["num_heads"], 0, device=0)
+    monkeypatch.delenv("TTX_PROFILE_GEMM")
+    g = tta.TranslationInferenceGreedySpeculative(pm, 150, 10, 3, PAD, BOS, EOS, c)
+    pm.kernel_profile()
+    out = g.generate_many(batches, in_flight=4, reorder=True, group_size=32, on_error="skip")
+    prof = pm.kernel_profile()
+    for a, b in zip(out, ref):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    assert g.model_calls_num == g_ref.model_calls_num
+    steps = g.stats_total["device"]["model_calls"]
+    assert len(pm._pool) >= 2 and steps > 0
+    assert prof["launches"] >= steps * (6 * pm.num_dec_layers + 1), (prof, steps)
+    assert prof["gemm_ms"] > 0 and prof["pair_overhead_ms"] >= 0
+    pm.close()
