@@ -2323,6 +2323,7 @@ static int beam_generate_impl(ttx_session* s, const int64_t* d_src, int B, int L
   HIP_TRY(hipSetDevice(m->device));
   release_retired();
   TTX_TRY(ensure_own_stream(s));
+  s->ev_used = 0;                     // profiling sessions: the event pairs of this call start from the first one
   HIP_TRY(hipEventRecord(s->ev_done, (hipStream_t)stream));
   HIP_TRY(hipStreamWaitEvent(s->own_stream, s->ev_done, 0));
   hipStream_t st = s->own_stream;
