@@ -51,7 +51,9 @@ struct Buf {
 //   GV_BIG    one workgroup walks all slices of its output tile (128x64 / 64x64 tiles by live row count)
 //   GV_SMALL  short dependent chains for steps of a few hundred rows: one wave per slice (32x32 tiles) for the K = 256
 //             GEMMs up to 768 columns, one workgroup per slice (split-K slabs, summed in order by k_finish_ln) for FFN2
-enum GemmVariant { GV_BIG = 0, GV_SMALL = 1 };
+//   GV_BIG_FFN2_SLABS  GV_BIG for every GEMM of the step except FFN2, which runs as in GV_SMALL (between small_rows and
+//             ffn2_slab_rows live rows one workgroup per 256-k slice beats the 128x64 / 64x64 tiles walking all 2 048 k's)
+enum GemmVariant { GV_BIG = 0, GV_SMALL = 1, GV_BIG_FFN2_SLABS = 2 };
 
 struct GraphKey {
   int B, Ls, N, D, max_len, mode, kcap, variant;   // mode: 0 speculative, 1 plain greedy, 2 per-row rule, 3 slot pool
@@ -113,6 +115,7 @@ struct ttx_session {
   bool attr_select = false, attr_step = false, attr_topk = false, attr_pool_select = false;
   // GEMM policy (all choices are between bit-identical evaluations, see GemmVariant)
   int small_rows = 2560;           // a verify step with fewer live rows than this runs under GV_SMALL (TTX_SMALL_ROWS)
+  int ffn2_slab_rows = 5600;       // ... and with fewer than this (and at least small_rows) under GV_BIG_FFN2_SLABS (TTX_FFN2_SLAB_ROWS; 0: never)
   // k_gemm24 picks the tiling per launch from the live row count: 128x64 tiles once there are big_min_tiles of them,
   // else 64x64 (TTX_BIG_MIN_TILES)
   int big_min_tiles = 400;
