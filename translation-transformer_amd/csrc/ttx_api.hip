@@ -304,6 +304,7 @@ extern "C" int ttx_session_create(ttx_model* m, ttx_session** out) {
   // tuning knob: the live row count below which a step takes the short-chain GEMM variant (identical bits)
   if (const char* e = getenv("TTX_SMALL_ROWS")) s->small_rows = std::max(0, atoi(e));
   if (const char* e = getenv("TTX_FFN2_SLAB_ROWS")) s->ffn2_slab_rows = std::max(0, atoi(e));
+  if (const char* e = getenv("TTX_QKV_SMALL_ROWS")) s->qkv_small_rows = std::max(0, atoi(e));
   // test hook: every attention launch on the streaming fallback kernel
   if (const char* e = getenv("TTX_ATTN_FALLBACK")) s->attn_fallback = atoi(e) != 0;
   s->host_timing = getenv("TTX_HOST_TIMING") != nullptr;
@@ -346,11 +347,15 @@ extern "C" void ttx_session_destroy(ttx_session* s) {
 // (encoder, cross K/V, full-prefix decoder) by their row count.
 static int variant_for_rows(const ttx_session* s, long long rows, bool step) {
   if (!step) return GV_BIG;
-  if (rows < s->small_rows) return GV_SMALL;
+  if (rows < s->qkv_small_rows) return GV_SMALL;
+  if (rows < s->small_rows) return GV_MID;
   return rows < s->ffn2_slab_rows ? GV_BIG_FFN2_SLABS : GV_BIG;
 }
-static int variant_main(int v) { return v == GV_BIG_FFN2_SLABS ? GV_BIG : v; }       // every GEMM of a step but FFN2
-static int variant_ffn2(int v) { return v == GV_BIG_FFN2_SLABS ? GV_SMALL : v; }
+// the step policy per GEMM shape (ttx_internal.h): QKV (N = 3d) | the d-wide K = d GEMMs and the classifier | FFN1 | FFN2
+static int variant_qkv(int v) { return v == GV_SMALL ? GV_SMALL : GV_BIG; }
+static int variant_dd(int v) { return (v == GV_SMALL || v == GV_MID) ? GV_SMALL : GV_BIG; }
+static int variant_ffn1(int v) { return v == GV_SMALL ? GV_SMALL : GV_BIG; }
+static int variant_ffn2(int v) { return v == GV_BIG ? GV_BIG : GV_SMALL; }
 
 // d-wide GEMM -> slab(s) -> k_finish_ln: Y = LN2?(LN((resid + bias) + X W^T))
 static int gemm_ln(ttx_session* s, hipStream_t st, const float* X, int ldx, int K, const float* W, const float* bias,
@@ -575,7 +580,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
   const int D1 = k.D + 1;
   const int RPS = step_rps(k.N, k.D);
   const int Mmax = k.B * RPS;
-  const int vm = variant_main(k.variant), vf = variant_ffn2(k.variant);
+  const int vq = variant_qkv(k.variant), vd = variant_dd(k.variant), v1 = variant_ffn1(k.variant), vf = variant_ffn2(k.variant);
   DecState* dst = s->state.as<DecState>();
   const int* m_ptr = &dst->m_rows;
   float* x = s->x.as<float>();
@@ -602,7 +607,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     const LayerW& w = m->dec[l];
     const bool last = (l == Ld - 1);
     float* qkv = s->qkv.as<float>() + (size_t)l * qkv_layer;
-    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, m_ptr, Mmax, 3 * d, d, false, 0, 0, vm));
+    TTX_TRY(launch_gemm(s, st, x, d, m->p(w.sa_in_w), d, m->p(w.sa_in_b), qkv, 3 * d, m_ptr, Mmax, 3 * d, d, false, 0, 0, vq));
     AttnArgs a{};
     a.q = qkv; a.ldq = 3 * d; a.k = qkv + d; a.v = qkv + 2 * d; a.ldkv = 3 * d; a.out = ao; a.d = d; a.scale = scale;
     a.tok = s->gen.as<int>(); a.pad = c.pad_token; a.st = dst; a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>();
@@ -611,8 +616,8 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D = k.D;
     TTX_TRY(launch_attn(ATT_STEP_SELF, s, st, a, k.B, H, RPS, kcap, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
-                    nullptr, x1, m_ptr, Mmax, vm));
-    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, m_ptr, Mmax, d, d, false, 0, 0, vm));
+                    nullptr, x1, m_ptr, Mmax, vd));
+    TTX_TRY(launch_gemm(s, st, x1, d, m->p(w.ca_in_w), d, m->p(w.ca_in_b), q2, d, m_ptr, Mmax, d, d, false, 0, 0, vd));
     AttnArgs ca{};
     ca.q = q2; ca.ldq = d; ca.k = s->memkv.as<float>() + (size_t)l * 2 * d; ca.v = ca.k + d; ca.ldkv = Ld * 2 * d;
     ca.out = ao; ca.d = d; ca.scale = scale; ca.Lk = k.Ls; ca.key_pad = s->src_valid.as<uint8_t>();
@@ -620,12 +625,12 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     ca.src_of = k.src_of; ca.src_len = k.src_len;
     TTX_TRY(launch_attn(ATT_STEP_CROSS, s, st, ca, k.B, H, RPS, k.Ls, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.ca_out_w), m->p(w.ca_out_b), x1, m->p(w.n2_w), m->p(w.n2_b), nullptr, nullptr,
-                    nullptr, x2, m_ptr, Mmax, vm));
-    TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, m_ptr, Mmax, F, d, true, 0, 0, vm));
+                    nullptr, x2, m_ptr, Mmax, vd));
+    TTX_TRY(launch_gemm(s, st, x2, d, m->p(w.l1_w), d, m->p(w.l1_b), hb, F, m_ptr, Mmax, F, d, true, 0, 0, v1));
     TTX_TRY(gemm_ln(s, st, hb, F, F, m->p(w.l2_w), m->p(w.l2_b), x2, m->p(w.n3_w), m->p(w.n3_b),
                     last ? m->p(m->dec_norm_w) : nullptr, last ? m->p(m->dec_norm_b) : nullptr, nullptr, last ? xf : x, m_ptr, Mmax, vf));
   }
-  TTX_TRY(launch_gemm(s, st, xf, d, m->p(m->cls_w), d, m->p(m->cls_b), logits, V, m_ptr, Mmax, V, d, false, 0, 0, vm));
+  TTX_TRY(launch_gemm(s, st, xf, d, m->p(m->cls_w), d, m->p(m->cls_b), logits, V, m_ptr, Mmax, V, d, false, 0, 0, vd));
   if (k.want_argmax) {
     hipLaunchKernelGGL(k_argmax, dim3(cdiv(Mmax, 4)), dim3(256), 0, st, logits, V, s->pred.as<int>(), m_ptr, Mmax);
     HIP_TRY(hipGetLastError());

@@ -53,7 +53,9 @@ struct Buf {
 //             GEMMs up to 768 columns, one workgroup per slice (split-K slabs, summed in order by k_finish_ln) for FFN2
 //   GV_BIG_FFN2_SLABS  GV_BIG for every GEMM of the step except FFN2, which runs as in GV_SMALL (between small_rows and
 //             ffn2_slab_rows live rows one workgroup per 256-k slice beats the 128x64 / 64x64 tiles walking all 2 048 k's)
-enum GemmVariant { GV_BIG = 0, GV_SMALL = 1, GV_BIG_FFN2_SLABS = 2 };
+//   GV_MID    between qkv_small_rows and small_rows: the short-chain kernels for the d-wide K = d GEMMs, the classifier and FFN2,
+//             the tiles for QKV and FFN1 (a 32x32 launch over 768 columns loses to 64x64 tiles from about 800 rows on)
+enum GemmVariant { GV_BIG = 0, GV_SMALL = 1, GV_BIG_FFN2_SLABS = 2, GV_MID = 3 };
 
 struct GraphKey {
   int B, Ls, N, D, max_len, mode, kcap, variant;   // mode: 0 speculative, 1 plain greedy, 2 per-row rule, 3 slot pool
@@ -114,7 +116,8 @@ struct ttx_session {
   bool attr_attn2[8] = {false, false, false, false, false, false, false, false};
   bool attr_select = false, attr_step = false, attr_topk = false, attr_pool_select = false;
   // GEMM policy (all choices are between bit-identical evaluations, see GemmVariant)
-  int small_rows = 2560;           // a verify step with fewer live rows than this runs under GV_SMALL (TTX_SMALL_ROWS)
+  int qkv_small_rows = 800;        // a verify step with fewer live rows than this runs under GV_SMALL (TTX_QKV_SMALL_ROWS)
+  int small_rows = 2000;           // ... with fewer than this under GV_MID (TTX_SMALL_ROWS)
   int ffn2_slab_rows = 5600;       // ... and with fewer than this (and at least small_rows) under GV_BIG_FFN2_SLABS (TTX_FFN2_SLAB_ROWS; 0: never)
   // k_gemm24 picks the tiling per launch from the live row count: 128x64 tiles once there are big_min_tiles of them,
   // else 64x64 (TTX_BIG_MIN_TILES)
