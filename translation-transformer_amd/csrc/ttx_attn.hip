@@ -519,6 +519,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 //             partials in LDS and then fold them in tile order (wave w finishing dims 8w + 4h .. +3): bit-identical results,
 //             four times the parallelism.  The host picks by launch size.
 constexpr int A3_QT = 32;            // step rows per wave
+#ifndef TTX_A3_SPLIT_BELOW
+#define TTX_A3_SPLIT_BELOW 1024      // launches with fewer units (slots x heads x 32-row tiles) share a unit's key tiles over four waves
+#endif
 
 // A3Tile = what one 32-key tile needs from memory, per lane.
 struct A3Tile {
@@ -915,7 +918,7 @@ static int launch_attn_mode(ttx_session* s, hipStream_t st, const AttnArgs& a, i
       const int qtiles = cdiv(q_per_group, A3_QT);
       const int keys3 = (MODE == ATT_STEP_SELF) ? max_keys + 1 + N * std::max(D, 0) : max_keys;
       const size_t lds3 = sizeof(float) * (size_t)A3_PART * cdiv(keys3, 32);
-      const bool split = s->attn_split != 0 && (s->attn_split > 0 || (long long)groups * H * qtiles < 2048) && lds3 <= 64 * 1024;
+      const bool split = s->attn_split != 0 && (s->attn_split > 0 || (long long)groups * H * qtiles < TTX_A3_SPLIT_BELOW) && lds3 <= 64 * 1024;
       if (split) {
         hipLaunchKernelGGL((k_attn3<MODE>), dim3(groups, H, qtiles), dim3(256), lds3, st, a);
       } else {
