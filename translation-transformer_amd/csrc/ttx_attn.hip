@@ -519,6 +519,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 //             partials in LDS and then fold them in tile order (wave w finishing dims 8w + 4h .. +3): bit-identical results,
 //             four times the parallelism.  The host picks by launch size.
 constexpr int A3_QT = 32;            // step rows per wave
+#ifndef TTX_A3S_WGS_PER_CU
+#define TTX_A3S_WGS_PER_CU 2         // grid of k_attn3s: workgroups per CU (two waves per SIMD are resident)
+#endif
 #ifndef TTX_A3_SPLIT_BELOW
 #define TTX_A3_SPLIT_BELOW 1024      // launches with fewer units (slots x heads x 32-row tiles) share a unit's key tiles over four waves
 #endif
@@ -924,7 +927,7 @@ static int launch_attn_mode(ttx_session* s, hipStream_t st, const AttnArgs& a, i
       } else {
         // a grid of the machine's size (two workgroups = eight waves per CU), every wave walking its share of the units
         const long long units = (long long)groups * H * qtiles;
-        const int wgs = (int)std::min<long long>((units + 3) / 4, 2LL * s->m->n_cu);
+        const int wgs = (int)std::min<long long>((units + 3) / 4, (long long)TTX_A3S_WGS_PER_CU * s->m->n_cu);
         hipLaunchKernelGGL((k_attn3s<MODE>), dim3(wgs), dim3(256), 0, st, a, H, qtiles);
       }
       HIP_TRY(hipGetLastError());

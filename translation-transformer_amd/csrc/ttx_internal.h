@@ -64,6 +64,9 @@ struct GraphKey {
   }
 };
 
+#ifndef TTX_BIG_MIN_TILES
+#define TTX_BIG_MIN_TILES 400
+#endif
 struct ttx_session {
   ttx_model* m;
   std::vector<Buf*> all;
@@ -121,7 +124,7 @@ struct ttx_session {
   int ffn2_slab_rows = 5600;       // ... and with fewer than this (and at least small_rows) under GV_BIG_FFN2_SLABS (TTX_FFN2_SLAB_ROWS; 0: never)
   // k_gemm24 picks the tiling per launch from the live row count: 128x64 tiles once there are big_min_tiles of them,
   // else 64x64 (TTX_BIG_MIN_TILES)
-  int big_min_tiles = 400;
+  int big_min_tiles = TTX_BIG_MIN_TILES;
   int attn_split = -1;             // -1 by launch size, 0 never, 1 always (key tiles of a head over 4 waves)
   bool attn_fallback = false;      // TTX_ATTN_FALLBACK=1 (test hook): every attention launch on the streaming kernel k_attn
   // profiling of the GEMM launches (bench.py roofline): a HIP event pair around every GEMM launch

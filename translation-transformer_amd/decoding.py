@@ -156,7 +156,7 @@ class TranslationInferenceGreedySpeculative:
         R = sum(sizes)
         # device group size: the given batch size is not binding any more; larger groups run the GEMMs at better MFMA
         # occupancy, but at least `in_flight` groups should exist so that tails overlap
-        if pool:      # slot pool: about 2 048 slots in flight in total (512 x 4 measured best)
+        if pool:      # slot pool: 512 slots x 5 pools for long lists (measured); short lists are split evenly
             gsz = int(group_size or os.environ.get("TTX_POOL_CAPACITY") or 512)
         else:
             gsz = int(group_size or min(256, max(max(sizes), -(-R // max(1, in_flight)))))
@@ -182,7 +182,7 @@ class TranslationInferenceGreedySpeculative:
         if pool:
             # continuous batching: every session keeps `gsz` slots filled from the sorted work list
             # (ttx_greedy_speculative_generate_pool)
-            n_sess = max(1, min(in_flight, max(1, 2048 // gsz), -(-R // 32)))     # short lists: several small pools overlap
+            n_sess = max(1, min(in_flight, max(1, 2560 // gsz), -(-R // 32)))     # five pools (sweeps: profiles/r03_sweep_c2_pools.txt)
             if os.environ.get("TTX_POOL_SESSIONS"):                               # experiments
                 n_sess = max(1, int(os.environ["TTX_POOL_SESSIONS"]))
             sessions = m.session_pool(n_sess)
