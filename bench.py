@@ -311,13 +311,16 @@ def predict_surface(tta, sd, timed, a, outs, raised, toks) -> dict:
         res, dt = loop(timed)
     ok = [i for i, o in enumerate(res) if o is not None]
     n = sum(int(timed[i].shape[0]) for i in ok)
-    return {"value": n / dt, "unit": "reactions/s", "window_batches": mod.predict_window,
-            "batches_served_from_look_ahead": mod._ahead.served if mod._ahead is not None else 0,
-            "look_ahead_windows": mod._ahead.windows if mod._ahead is not None else 0,
-            "look_ahead_decode_seconds": mod._ahead.decode_seconds if mod._ahead is not None else 0.0, "loop_seconds": dt,
-            "identical_to_timed_outputs": sorted(set(range(len(timed))) - set(ok)) == sorted(raised)
-            and all(torch.equal(res[i], outs[i]) for i in ok),
-            "model_calls": mod.generator.model_calls_num}
+    rec = {"value": n / dt, "unit": "reactions/s", "window_batches": mod.predict_window,
+           "batches_served_from_look_ahead": mod._ahead.served if mod._ahead is not None else 0,
+           "look_ahead_windows": mod._ahead.windows if mod._ahead is not None else 0,
+           "look_ahead_decode_seconds": mod._ahead.decode_seconds if mod._ahead is not None else 0.0, "loop_seconds": dt,
+           "identical_to_timed_outputs": sorted(set(range(len(timed))) - set(ok)) == sorted(raised)
+           and all(torch.equal(res[i], outs[i]) for i in ok),
+           "model_calls": mod.generator.model_calls_num}
+    if mod.native is not None:
+        mod.native.close()                # sessions (and their streams) go back before the next measurement builds its model
+    return rec
 
 
 def smiles_pipeline(tta, sd, a, src_rows, tgt_rows, token_batches) -> dict:
@@ -386,6 +389,8 @@ def smiles_pipeline(tta, sd, a, src_rows, tgt_rows, token_batches) -> dict:
         dt, t_tok, t_write, n_lines, loader = run()
     same_tokens = len(loader) == len(token_batches) and all(torch.equal(b["src_tokens"], t) for b, t in zip(loader, token_batches))
     n = len(src_lines)
+    if mod.native is not None:
+        mod.native.close()
     return {"value": n / dt, "unit": "reactions/s (SMILES strings in -> CSV rows out)", "reactions": n, "csv_rows": n_lines,
             "seconds": {"total": dt, "tokenize_and_collate": t_tok, "write_csv_incl_detokenize": t_write,
                         "decode_on_gpu_and_rest": dt - t_tok - t_write},
@@ -498,6 +503,7 @@ def measure_c2(ctx: Ctx, a, tta) -> dict:
         line["device_src_tokens_padded"] = stats["device"]["src_tokens_padded"]
         line["config"]["pools"] = {"slots_per_pool": getattr(gen, "last_group_size", None)}
     if a.timed_only:
+        model.close()
         return line
     # ---- beside the headline: N = 1 ("N=1 reported alongside"), the batches as given, one at a time
     decode(make_gen(model, 1), timed)
@@ -536,6 +542,10 @@ def measure_c2(ctx: Ctx, a, tta) -> dict:
                                               "identical_to_row_scheduled_outputs": sorted(set(range(len(timed))) - set(ok2)) == sorted(raised)
                                               and all(torch.equal(given[i], outs[i]) for i in ok2),
                                               "model_calls": g2.model_calls_num}
+    # every further leg builds a model of its own: this one's sessions, workspaces and streams go back first (a process's later
+    # streams share hardware queues less evenly than its first ones, DESIGN.md §4.3 — each leg should see what a fresh process sees)
+    model.close()
+    torch.cuda.empty_cache()
     line["predict_step_surface"] = predict_surface(tta, sd, timed, a, outs, raised, (PAD, BOS, EOS, C_TOK, V))
     if not a.no_sub_records:
         n0 = a.warmup * a.batch_size
@@ -587,8 +597,6 @@ def measure_c2(ctx: Ctx, a, tta) -> dict:
                                           f"oracle/ (full-prefix recompute like the reference), torch {torch.__version__} fp32",
                                 "seconds": cpu_s, "model_calls": og.model_calls_num}
         line["parity"] = {"rows_token_identical_to_oracle": rows_same, "rows_checked": n_cpu, "batches_identical": same}
-    model.close()                         # sessions and workspaces of this measurement go back before the next one starts
-    torch.cuda.empty_cache()
     return line
 
 
@@ -665,6 +673,7 @@ def measure_beam(ctx: Ctx, a, tta, name: str, steps: int, warmup: int, full: boo
     rec["hbm_algorithmic"] = {"bytes_per_reaction": w_timed["bytes"] / max(1.0, n_reactions / world),
                               "achieved_GBs": w_timed["bytes"] / elapsed / 1e9, "frac_of_peak": w_timed["bytes"] / elapsed / 1e9 / PEAK_HBM_GBS}
     if a.timed_only:
+        model.close()
         return rec
     if full:
         if pooled:
@@ -684,6 +693,8 @@ def measure_beam(ctx: Ctx, a, tta, name: str, steps: int, warmup: int, full: boo
                                "top1_identical_to_timed_run": sum(int(torch.equal(x[:, 0, :min(x.shape[2], y.shape[2])],
                                                                                   y[:, 0, :min(x.shape[2], y.shape[2])]))
                                                                   for x, y in zip(other, outs)), "batches": len(outs)}
+    model.close()                         # the profiling model below takes over this one's sessions' streams
+    torch.cuda.empty_cache()
     if not a.no_profile:
         os.environ["TTX_PROFILE_GEMM"] = "1"
         pm = tta.NativeTransformer(sd, num_heads=8, pad_token_idx=PAD, device=ctx.local_rank)
@@ -730,8 +741,6 @@ def measure_beam(ctx: Ctx, a, tta, name: str, steps: int, warmup: int, full: boo
                                "seconds": cpu_s, "model_calls": og.model_calls_num}
         rec["parity"] = {"top1_rows_token_identical_to_oracle": top1, "rows_checked": n_cpu,
                          "hypotheses_token_identical_to_oracle": all_ranks, "hypotheses_checked": total}
-    model.close()
-    torch.cuda.empty_cache()
     return rec
 
 
