@@ -1325,6 +1325,7 @@ static int generate_many_impl(ttx_session** sessions, int n_sessions, int n_batc
     for (int i = 0; i < n_batches; ++i)
       if (!d_traj[i] || !d_fin || !d_fin[i]) return fail(TTX_ERR_INVALID, "missing trace buffer for a batch");
   for (int i = 0; i < n_batches; ++i) TTX_TRY(gen_validate(sessions[0], d_src[i], B[i], Ls[i], p, d_out[i], false));
+  if (sessions[0]->profile) n_sessions = 1;      // profiling: one batch at a time, so that an event pair times its own launch
   HIP_TRY(hipSetDevice(sessions[0]->m->device));
   release_retired();
   hipStream_t caller = (hipStream_t)stream;
@@ -1815,6 +1816,7 @@ extern "C" int ttx_beam_speculative_generate_many(ttx_session** sessions, int n_
   EventGuard ready;
   HIP_TRY(hipEventCreateWithFlags(&ready.e, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(ready.e, (hipStream_t)stream));
+  if (sessions[0]->profile) n_sessions = 1;      // profiling: one batch at a time (see the greedy driver)
   const int n_jobs = std::min(n_sessions, n_batches);
   for (int i = 0; i < n_jobs; ++i) {
     TTX_TRY(ensure_own_stream(sessions[i]));
