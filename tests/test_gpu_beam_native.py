@@ -146,23 +146,24 @@ def _compare_with_oracle(tta, native, oracle, sel, params, label, modes=(False, 
 
 def test_config_c4_full_size_matches_oracle(tta, trained_full_state):
     """BASELINE config C4 at its real sizes: 6+6 layers of d=256 / 8 heads / FFN 2048, beam-speculative n_best 10, bs 8,
-    n_drafts 2, draft_len 10, max_len 200: the full batch of 8 sources in the mode the bench times (all drafts) and a batch of 3
-    in smart-drafts mode (the CPU oracle takes about 8 s per source and mode)."""
+    n_drafts 2, draft_len 10, max_len 200: five sources in the mode the bench times (all drafts) and two in
+    smart-drafts mode (the CPU oracle takes about 8 s per source and mode; bench.py checks a full batch of 8 against the oracle on
+    every run, and tests/test_gpu_beam_pool.py runs the full configuration pooled against per-batch calls)."""
     from oracle.model import OracleTransformer, config_from_state
     st = trained_full_state(6)
     native = tta.NativeTransformer(st, 8, 0, device=0)
     assert native.num_enc_layers == 6 and native.num_dec_layers == 6
     oracle = OracleTransformer(config_from_state(st, 8), st)
     src, _, _, _ = fixture_tokens()
-    rows = [0, 2, 3, 4, 5, 6, 8, 9]
+    rows = [0, 2, 4, 6, 9]
     sel = src[rows]
     sel = sel[:, :int((sel != PAD).sum(1).max())]
     n_diff, n_total = _compare_with_oracle(tta, native, oracle, sel, (10, 10, 2, 200), "C4", modes=(False,))
-    sel4 = src[[0, 5, 8]]
+    sel4 = src[[0, 8]]
     sel4 = sel4[:, :int((sel4 != PAD).sum(1).max())]
-    d4, t4 = _compare_with_oracle(tta, native, oracle, sel4, (10, 10, 2, 200), "C4 (3 sources)", modes=(True,))
+    d4, t4 = _compare_with_oracle(tta, native, oracle, sel4, (10, 10, 2, 200), "C4 (2 sources)", modes=(True,))
     n_diff, n_total = n_diff + d4, n_total + t4
-    assert n_total == (8 + 3) * 10    # a differing lower rank only passes _compare_with_oracle as a proven near-tie (2e-3)
+    assert n_total == (5 + 2) * 10    # a differing lower rank only passes _compare_with_oracle as a proven near-tie (2e-3)
     print("C4: hypotheses differing at a proven near-tie:", n_diff)
 
 
@@ -253,7 +254,7 @@ def test_standard_beam_search_small_cases_match_oracle(tta):
 
 
 def test_randomised_settings_match_oracle(tta):
-    """Twenty-two random (rows, n_best, n_drafts, draft_len, max_len, draft mode) settings on the tiny model: every hypothesis and
+    """Eighteen random (rows, n_best, n_drafts, draft_len, max_len, draft mode) settings on the tiny model: every hypothesis and
     the counters equal the oracle's; where the oracle's loop does not terminate within the guard, neither does the native one."""
     from oracle.model import OracleTransformer, config_from_state
     from oracle.spec_beam import BeamSearchSpeculativeOracle
@@ -263,7 +264,7 @@ def test_randomised_settings_match_oracle(tta):
     src, _, c, V = fixture_tokens()
     rng = np.random.default_rng(20251004)
     compared = guarded = 0
-    for trial in range(22):
+    for trial in range(18):
         rows = rng.choice(10, size=int(rng.integers(1, 6)), replace=False).tolist()
         nbest = int(rng.choice([1, 2, 3, 5, 8]))
         N = int(rng.choice([1, 2, 3, 7, 23]))
@@ -289,7 +290,7 @@ def test_randomised_settings_match_oracle(tta):
                (ref.model_calls_num, ref.accepted_tokens_num, ref.produced_non_pad_tokens), label
         compared += 1
     print(f"randomised beam-speculative settings: {compared} compared, {guarded} hit the max_steps guard on both sides")
-    assert compared >= 14
+    assert compared >= 11
 
 
 def test_randomised_standard_beam_search_matches_oracle(tta):
