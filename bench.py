@@ -200,11 +200,19 @@ class Ctx:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(self, fn, repeats: int):
+    def timed(self, fn, repeats: int, local: bool = False):
         """`repeats` runs of fn() -> result, each bracketed by barrier + synchronize on both sides, elapsed = MAX over ranks.
-        Returns (sorted list of seconds, result of the median run, all seconds in run order)."""
+        Returns (sorted list of seconds, result of the median run, all seconds in run order).  `local`: a measurement only
+        rank 0 makes (the records beside the headline): synchronize only, no collective — the other ranks are not there."""
         runs = []
         for _ in range(max(1, repeats)):
+            if local:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = fn()
+                torch.cuda.synchronize()
+                runs.append((time.perf_counter() - t0, res))
+                continue
             self.barrier()
             t0 = time.perf_counter()
             res = fn()
@@ -507,7 +515,7 @@ def measure_c2(ctx: Ctx, a, tta) -> dict:
         return line
     # ---- beside the headline: N = 1 ("N=1 reported alongside"), the batches as given, one at a time
     decode(make_gen(model, 1), timed)
-    s1, (o1, r1, g1), _ = ctx.timed(lambda: decode(make_gen(model, 1), timed), 1)
+    s1, (o1, r1, g1), _ = ctx.timed(lambda: decode(make_gen(model, 1), timed), 1, local=True)
     line["n_drafts_1"] = {"value": sum(int(timed[i].shape[0]) for i in range(len(timed)) if i not in r1) / s1[0], "unit": "reactions/s",
                           "model_calls": g1.model_calls_num,
                           "rows_identical_to_n_drafts_3": int(sum(int((x[:, 0] == y[:, 0]).all(dim=1).sum()) for x, y in zip(o1, outs)
@@ -678,16 +686,16 @@ def measure_beam(ctx: Ctx, a, tta, name: str, steps: int, warmup: int, full: boo
     if full:
         if pooled:
             run(make_gen(model, smart), timed, a.inflight, False)
-            s2, (given, gg), _ = ctx.timed(lambda: run(make_gen(model, smart), timed, a.inflight, False), 1)
+            s2, (given, gg), _ = ctx.timed(lambda: run(make_gen(model, smart), timed, a.inflight, False), 1, local=True)
             rec["batches_as_given_in_flight"] = {"value": n_reactions / world / s2[0], "unit": "reactions/s",
                                                  "identical_to_pooled_outputs": all(torch.equal(x, y) for x, y in zip(given, outs))
                                                  and gg.model_calls_num == gen.model_calls_num}
-        s1, (seq, g1), _ = ctx.timed(lambda: run(make_gen(model, smart), timed, 1, False), 1)
+        s1, (seq, g1), _ = ctx.timed(lambda: run(make_gen(model, smart), timed, 1, False), 1, local=True)
         rec["one_batch_at_a_time"] = {"value": n_reactions / world / s1[0], "unit": "reactions/s",
                                       "identical_to_timed_outputs": all(torch.equal(x, y) for x, y in zip(seq, outs))
                                       and g1.model_calls_num == gen.model_calls_num}
     run(make_gen(model, not smart), timed, a.inflight, pooled)
-    s3, (other, g3), _ = ctx.timed(lambda: run(make_gen(model, not smart), timed, a.inflight, pooled), 1)
+    s3, (other, g3), _ = ctx.timed(lambda: run(make_gen(model, not smart), timed, a.inflight, pooled), 1, local=True)
     rec["other_draft_mode"] = {"smart_drafts_mode": not smart, "value": n_reactions / world / s3[0], "unit": "reactions/s",
                                "model_calls": g3.model_calls_num,
                                "top1_identical_to_timed_run": sum(int(torch.equal(x[:, 0, :min(x.shape[2], y.shape[2])],

@@ -97,11 +97,18 @@ def test_two_rank_bench_data_path_equals_single_process(tmp_path):
                MASTER_PORT=str(_free_port()))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup), "--timed-only"]
+    # the driver's form of the command (no --timed-only): after the headline rank 0 goes on alone with the records beside it
+    # (N = 1 drafts, one batch at a time, the surface, the roofline pass) while rank 1 waits at the final barrier — none of those
+    # may use a collective (round 3 shipped one for a while: "connection closed by peer" at N > 1)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.strip().split("\n") if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == steps and line["config"]["reactions"] == world * steps * bs
+    assert line["scaling"] == "weak" and line["repeats"]["n"] == 5
+    for key in ("n_drafts_1", "one_batch_at_a_time", "predict_step_surface", "roofline"):
+        assert key in line, key
+    assert "c3" not in line and "cpu_baseline" not in line          # single-GPU records only at N = 1
     got = np.load(dump)
     assert got.shape == (world * steps * bs, 1, 200)
     # the same rows, one process, one batch at a time
