@@ -66,3 +66,34 @@ def test_roofline_pass_is_the_last_launches_and_reduced(tmp_path):
     entry = json.loads(out_json.read_text())[0]
     assert entry["launches"] == 6 and entry["command_key"] == {"config": "c2", "steps": 20, "warmup": 5, "schedule": "rows", "inflight": 8}
     assert abs(entry["bytes_per_launch"] - (2 * 1000 + 500) * 1024) < 1e-6
+
+
+def test_timeline_and_pmc_summaries_on_a_synthetic_trace(tmp_path):
+    """tools/trace_timeline.py (last busy window with >= 1000 launches, busy share, kernels running at once),
+    tools/pmc_by_kernel.py and tools/pmc_top_dispatches.py on small synthetic rocprofv3 CSVs."""
+    gemm, ln = "void ttx::k_gemm24<4>(ttx::GemmArgs)", "ttx::k_finish_ln<4>(ttx::FinishArgs)"
+    rows = [(1, gemm, 0, 1000)]                                       # an early, small window
+    t = 50_000_000
+    for i in range(600):                                              # the window of interest: two streams, overlapping halves
+        rows.append((2, gemm, t + 2000 * i, 1500))
+        rows.append((3, ln, t + 2000 * i + 1000, 1500))
+    _trace(tmp_path / "t.csv", rows)
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "trace_timeline.py"), str(tmp_path / "t.csv"), "1", "4"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "1200 launches on 2 streams" in r.stdout
+    assert "k_gemm24<4>" in r.stdout and "600 launches" in r.stdout
+    body = [l for l in r.stdout.split("\n") if l.strip().startswith(("0 |", "1 |", "2 |", "3 |"))]
+    assert len(body) == 4
+    for line in body:                                                 # every slice: always busy, 1.5 kernels at once
+        cols = [c.strip() for c in line.split("|")]
+        assert abs(float(cols[1]) - 1.0) < 0.02 and abs(float(cols[2]) - 1.5) < 0.05, line
+    _counters(tmp_path / "cc.csv", rows[:5], "SQ_WAVE_CYCLES", 10.0)
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_by_kernel.py"), str(tmp_path / "cc.csv"), "ttx"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "ttx::k_gemm24<4> | 3 | 30" in r.stdout and "ttx::k_finish_ln<4> | 2 | 20" in r.stdout
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_top_dispatches.py"), str(tmp_path / "cc.csv"), "k_gemm24", "2",
+                        str(tmp_path / "t.csv")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("ttx::k_gemm24<4>") == 2 and "SQ_WAVE_CYCLES" in r.stdout
