@@ -318,7 +318,10 @@ int ttx_debug_step_snapshot(ttx_session* s, int32_t* info, float* h_logits, int3
  * every GEMM launch) and launch count of the generate calls on this session since the previous read (reading resets the sums);
  * `empty_pair_ms` is what the bracketing adds to a launch's figure, calibrated on the same stream with pairs around a kernel of
  * known duration (pair time minus the realtime ticks the kernel saw go by; median of 32).  Only collected when the session was
- * created with TTX_PROFILE_GEMM=1 in the environment (that session launches eagerly, without graphs). */
+ * created with TTX_PROFILE_GEMM=1 in the environment (that session launches eagerly, without graphs).  The *_pool and *_many
+ * entry points run the sessions of a call ONE AFTER ANOTHER when sessions[0] is a profiling session (each pool decodes the share of
+ * the work list it takes when all start together), so that an event pair times its own launch and not the other sessions' kernels;
+ * every session of the call must then be a profiling one (NativeTransformer built under TTX_PROFILE_GEMM=1 sees to that). */
 int ttx_last_kernel_profile(ttx_session* s, double* gemm_ms, int64_t* gemm_launches, double* empty_pair_ms);
 
 /* Development aid (tools/bench_gemm.py): times one GEMM shape (K = 64, 128 or a multiple of 256) in isolation on random
