@@ -569,6 +569,7 @@ struct StepCtx {
   const float* vcache = nullptr;
   const int* src_of = nullptr;     // running row -> source row (tree decoding)
   const int* src_len = nullptr;    // slot pool: source keys per slot
+  const int* cache_slot = nullptr; // batch pool: running row (candidate) -> slot of its KV cache
   bool want_argmax = true;
   int variant = GV_BIG;            // GemmVariant of this step's launches (bit-identical results; chosen from the live row count)
 };
@@ -613,7 +614,7 @@ static int run_step(ttx_session* s, hipStream_t st, const StepCtx& k, int kcap) 
     a.tok = s->gen.as<int>(); a.pad = c.pad_token; a.st = dst; a.act_idx = s->act_idx.as<int>(); a.front = s->front.as<int>();
     a.kcache = (k.kcache ? k.kcache : s->kcache.as<float>()) + (size_t)l * cache_layer;
     a.vcache = (k.vcache ? k.vcache : s->vcache.as<float>()) + (size_t)l * cache_layer;
-    a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D = k.D;
+    a.cache_seq_stride = cache_seq; a.gen_ld = k.gen_ld; a.N = k.N; a.D = k.D; a.cache_slot = k.cache_slot;
     TTX_TRY(launch_attn(ATT_STEP_SELF, s, st, a, k.B, H, RPS, kcap, k.N, D1));
     TTX_TRY(gemm_ln(s, st, ao, d, d, m->p(w.sa_out_w), m->p(w.sa_out_b), x, m->p(w.n1_w), m->p(w.n1_b), nullptr, nullptr,
                     nullptr, x1, m_ptr, Mmax, vd));
@@ -1928,13 +1929,13 @@ static int bpool_start(BeamPoolJob& j, ttx_session* s, hipStream_t st, int C, in
   need(s->drafts, MC * j.N * j.D0 * 4);
   need(s->gen, MC * j.gen_ld * 4); need(s->front, MC * 4); need(s->act_idx, MC * 4);
   need(s->pred, Mmax * 4); need(s->state, sizeof(DecState)); need(s->logits, Mmax * V * 4);
-  for (int i = 0; i < 2; ++i) { need(s->tk[i], (size_t)Ld * MC * j.Lc * d * 4); need(s->tv[i], (size_t)Ld * MC * j.Lc * d * 4); }
+  need(s->tk[0], (size_t)Ld * MC * j.Lc * d * 4); need(s->tv[0], (size_t)Ld * MC * j.Lc * d * 4);      // one buffer: candidate -> slot map
   need(s->t_prev_len, MC * 4); need(s->t_slot_of, MC * 4); need(s->t_src_of, MC * 4); need(s->bp_cand_len, MC * 4);
   need(s->bs_cand_next, MC * j.gen_ld * 8); need(s->bs_len_next, MC * 4); need(s->bs_fin_next, MC); need(s->bs_logp_next, MC * 4);
   need(s->bs_len, MC * 4); need(s->bs_fin, MC); need(s->bs_active, MC); need(s->bs_logp, MC * 4); need(s->bs_per_cand, MC * 4);
   need(s->bs_best_n, MC * 4); need(s->bs_best_slot, MC * 4); need(s->bs_chosen, MC * j.D0 * 8);
   need(s->bs_hit, MC * (size_t)j.N * j.D0); need(s->bs_mark, MC);            // bs_mark: the live flags of the pool
-  need(s->bs_parent, MC * 4); need(s->bs_parent_draft, MC * 4); need(s->bp_cand, MC * 8);      // cand_dl, cand_batch
+  need(s->bs_parent, MC * 4); need(s->bs_parent_draft, MC * 4); need(s->bp_cand, MC * 16);     // cand_dl, cand_batch, cache_slot, cache_slot_parent
   need(s->bs_cnt, sizeof(BeamCounters));
   const size_t dl1 = (size_t)j.D0 + 1;
   need(s->leaf_score, MC * dl1 * j.K * 4); need(s->leaf_tok, MC * dl1 * j.K * 4); need(s->leaf_cnt, MC * dl1 * 4);
@@ -1983,7 +1984,7 @@ static int bpool_start(BeamPoolJob& j, ttx_session* s, hipStream_t st, int C, in
     a.bat_id = bb; a.bat_iter = bb + C; a.bat_dl = bb + 2 * C; a.bat_grp = bb + 3 * C; a.bat_live = bb + 4 * C; a.bat_nfin = bb + 5 * C;
     a.bat_longest_fin = bb + 6 * C; a.bat_longest_cur = bb + 7 * C; a.bat_state = bb + 8 * C; a.bat_given = bb + 9 * C;
   }
-  a.cand_dl = s->bp_cand.as<int>(); a.cand_batch = a.cand_dl + j.MC;
+  a.cand_dl = s->bp_cand.as<int>(); a.cand_batch = a.cand_dl + j.MC; a.cache_slot = a.cand_dl + 2 * j.MC; a.cache_slot_parent = a.cand_dl + 3 * j.MC;
   a.tok = s->bp_tok.as<int>(); a.drafts_all = s->bs_drafts_src.as<int>();
   a.cand_next = s->bs_cand_next.as<int64_t>(); a.len_next = s->bs_len_next.as<int>(); a.fin_next = s->bs_fin_next.as<uint8_t>();
   a.logp_next = s->bs_logp_next.as<float>(); a.parent = s->bs_parent.as<int>(); a.parent_draft = s->bs_parent_draft.as<int>();
@@ -2047,10 +2048,13 @@ static int bpool_enqueue_iter(const BeamPoolJob& j, int cur, int variant) {
   hipLaunchKernelGGL(k_bsp_prep, dim3(MC), dim3(256), 0, st, j.a);
   HIP_TRY(hipGetLastError());
   const int nxt = cur ^ 1;
+  (void)nxt;
   TreeCacheArgs ca{};
   ca.len = s->bs_len.as<int>(); ca.parent = s->bs_parent.as<int>(); ca.parent_draft = s->bs_parent_draft.as<int>();
   ca.prev_len = s->t_prev_len.as<int>(); ca.active = s->bs_active.as<uint8_t>();
-  ca.k_old = s->tk[cur].as<float>(); ca.v_old = s->tv[cur].as<float>(); ca.k_new = s->tk[nxt].as<float>(); ca.v_new = s->tv[nxt].as<float>();
+  // ONE cache buffer and a candidate -> slot map (k_bsp_select): most children append in their parent's slot, few copy
+  ca.k_old = s->tk[0].as<float>(); ca.v_old = s->tv[0].as<float>(); ca.k_new = s->tk[0].as<float>(); ca.v_new = s->tv[0].as<float>();
+  ca.slot_parent = j.a.cache_slot_parent; ca.slot_self = j.a.cache_slot;
   ca.cache_layer_stride = cache_layer; ca.cache_seq_stride = cache_seq;
   ca.qkv_prev = s->qkv.as<float>(); ca.qkv_layer_stride = (long long)MC * step_rps(j.N, dl) * 3 * d;
   ca.prev_slot_of = s->t_slot_of.as<int>(); ca.prev_N = j.N; ca.prev_D = dl; ca.d = d;
@@ -2065,7 +2069,8 @@ static int bpool_enqueue_iter(const BeamPoolJob& j, int cur, int variant) {
   HIP_TRY(hipGetLastError());
   StepCtx k{};
   k.B = MC; k.Ls = j.Ls_cap; k.N = j.N; k.D = dl; k.Lc = j.Lc; k.gen_ld = j.gen_ld; k.max_len = j.p.max_len;
-  k.kcache = s->tk[nxt].as<float>(); k.vcache = s->tv[nxt].as<float>(); k.src_of = s->t_src_of.as<int>(); k.src_len = s->bp_cand_len.as<int>();
+  k.kcache = s->tk[0].as<float>(); k.vcache = s->tv[0].as<float>(); k.cache_slot = j.a.cache_slot;
+  k.src_of = s->t_src_of.as<int>(); k.src_len = s->bp_cand_len.as<int>();
   k.want_argmax = false; k.variant = variant;
   TTX_TRY(run_step(s, st, k, std::min(j.p.max_len, ((j.p.max_len + 63) / 64) * 64)));
   BeamHitsArgs ha{};

@@ -150,8 +150,9 @@ __global__ __launch_bounds__(64) void k_attn(AttnArgs a) {
       const int f = a.front[b];
       const int* tk = a.tok + (size_t)b * a.gen_ld;
       const int pad = a.pad;
-      const float* kc = a.kcache + (size_t)b * a.cache_seq_stride + hd;
-      const float* vc = a.vcache + (size_t)b * a.cache_seq_stride + hd;
+      const size_t cb = a.cache_slot ? a.cache_slot[b] : b;      // the sequence's slot in the cache (batch pool: candidate -> slot map)
+      const float* kc = a.kcache + cb * a.cache_seq_stride + hd;
+      const float* vc = a.vcache + cb * a.cache_seq_stride + hd;
       const float* kb = a.k + srow0 * a.ldkv + hd;
       const float* vb = a.v + srow0 * a.ldkv + hd;
       const int ld = a.ldkv, dd = a.d;
@@ -452,8 +453,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       const int f = a.front[b];
       const int* tk = a.tok + (size_t)b * a.gen_ld;
       const int pad = a.pad;
-      const float* kc = a.kcache + (size_t)b * a.cache_seq_stride + hd;
-      const float* vc = a.vcache + (size_t)b * a.cache_seq_stride + hd;
+      const size_t cb = a.cache_slot ? a.cache_slot[b] : b;      // the sequence's slot in the cache (batch pool: candidate -> slot map)
+      const float* kc = a.kcache + cb * a.cache_seq_stride + hd;
+      const float* vc = a.vcache + cb * a.cache_seq_stride + hd;
       const float* kb = a.k + srow0 * a.ldkv + hd;
       const float* vb = a.v + srow0 * a.ldkv + hd;
       const int ld = a.ldkv, dd = a.d;
@@ -585,8 +587,9 @@ __device__ __forceinline__ A3Unit a3_unit(const AttnArgs& a, int slot, int head,
     c.n_lo = n_lo;
     c.kr0 = 1 + n_lo * D;
     c.tk = a.tok + (size_t)b * a.gen_ld;
-    c.klin = a.kcache + (size_t)b * a.cache_seq_stride + hd;
-    c.vlin = a.vcache + (size_t)b * a.cache_seq_stride + hd;
+    const size_t cb = a.cache_slot ? (size_t)a3_uniform(a.cache_slot[b]) : (size_t)b;
+    c.klin = a.kcache + cb * a.cache_seq_stride + hd;
+    c.vlin = a.vcache + cb * a.cache_seq_stride + hd;
     c.kb = a.k + srow0 * a.ldkv + hd;
     c.vb = a.v + srow0 * a.ldkv + hd;
     c.kvalid = nullptr;

@@ -99,6 +99,7 @@ struct AttnArgs {
   const int* src_of;               // step modes: running row -> source row of the encoder memory (null: identity)
   const int* src_len;              // STEP_CROSS: keys of each row's source (null: Lk for every row) — slot pool
   const float* kcache; const float* vcache; long long cache_seq_stride;  // floats per sequence in the cache
+  const int* cache_slot;           // STEP_SELF: running row -> its sequence's slot in the cache (null: the row index itself)
   int gen_ld; int N; int D;
 };
 

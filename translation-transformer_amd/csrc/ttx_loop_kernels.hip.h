@@ -889,6 +889,9 @@ struct TreeCacheArgs {
   const float* qkv_prev; long long qkv_layer_stride;    // previous step's packed QKV rows, [Ld][M][3d]
   const int* prev_slot_of;                               // previous step: candidate -> slot in its compact active list (-1: inactive)
   int prev_N, prev_D, d;
+  // batch pool: ONE cache buffer (k_old == k_new) and a candidate -> slot map.  A child that took over its parent's slot only
+  // appends; the others copy the parent's rows into a slot no candidate of this iteration descends from (k_bsp_select's choice).
+  const int* slot_parent; const int* slot_self;          // null: cache row = candidate index, two buffers
 };
 
 __global__ __launch_bounds__(256) void k_tree_cache(TreeCacheArgs a) {
@@ -898,14 +901,17 @@ __global__ __launch_bounds__(256) void k_tree_cache(TreeCacheArgs a) {
   if (p < 0) return;                                     // fresh candidate (<BOS> only): nothing cached yet
   const int lc = a.len[c], lp = a.prev_len[p];
   const int per_row = a.d / 4;
-  const float* ko = a.k_old + (size_t)l * a.cache_layer_stride + (size_t)p * a.cache_seq_stride;
-  const float* vo = a.v_old + (size_t)l * a.cache_layer_stride + (size_t)p * a.cache_seq_stride;
-  float* kn = a.k_new + (size_t)l * a.cache_layer_stride + (size_t)c * a.cache_seq_stride;
-  float* vn = a.v_new + (size_t)l * a.cache_layer_stride + (size_t)c * a.cache_seq_stride;
+  const int sp = a.slot_parent ? a.slot_parent[c] : p, sc = a.slot_self ? a.slot_self[c] : c;
+  const float* ko = a.k_old + (size_t)l * a.cache_layer_stride + (size_t)sp * a.cache_seq_stride;
+  const float* vo = a.v_old + (size_t)l * a.cache_layer_stride + (size_t)sp * a.cache_seq_stride;
+  float* kn = a.k_new + (size_t)l * a.cache_layer_stride + (size_t)sc * a.cache_seq_stride;
+  float* vn = a.v_new + (size_t)l * a.cache_layer_stride + (size_t)sc * a.cache_seq_stride;
   const int n_old = lp - 1;                              // positions the parent had cached
-  for (int e = threadIdx.x; e < n_old * per_row; e += blockDim.x) {
-    reinterpret_cast<float4*>(kn)[e] = reinterpret_cast<const float4*>(ko)[e];
-    reinterpret_cast<float4*>(vn)[e] = reinterpret_cast<const float4*>(vo)[e];
+  if (!(a.slot_self && sp == sc)) {                      // (in its parent's slot the rows are already there)
+    for (int e = threadIdx.x; e < n_old * per_row; e += blockDim.x) {
+      reinterpret_cast<float4*>(kn)[e] = reinterpret_cast<const float4*>(ko)[e];
+      reinterpret_cast<float4*>(vn)[e] = reinterpret_cast<const float4*>(vo)[e];
+    }
   }
   const int n_new = (lc - 1) - n_old;                    // parent's front row + accepted draft rows
   const int slot = a.prev_slot_of[p];
@@ -1341,6 +1347,7 @@ struct BeamPoolArgs {
   int64_t* cand_next; int* len_next; uint8_t* fin_next; float* logp_next; int* parent; int* parent_draft;
   int* gen; int* front; int* len; uint8_t* active; uint8_t* finished; uint8_t* live; float* logp; int* per_cand; int* drafts32;
   int* cand_dl; int* cand_batch;
+  int* cache_slot; int* cache_slot_parent;        // candidate -> slot of its KV cache; slot its parent's rows sit in (k_tree_cache)
   const int* chosen_slot; const int64_t* chosen;
   const float* leaf_score; const int* leaf_tok; const int* leaf_cnt;
   BeamCounters* cnt; const BeamPoolIo* io; BeamPoolHost* host; int* dev_summary;   // dev_summary [4]: live sources, running candidates, error, -
@@ -1358,6 +1365,7 @@ __global__ void k_bsp_init(BeamPoolArgs a, int* src_of, int* cand_src_len) {
   for (int i = tid; i < MC; i += nth) {
     a.len_next[i] = 1; a.fin_next[i] = 1; a.logp_next[i] = 0.f; a.parent[i] = -1; a.parent_draft[i] = 0;
     a.active[i] = 0; a.finished[i] = 1; a.live[i] = 0; a.per_cand[i] = 0; a.cand_dl[i] = a.D0; a.cand_batch[i] = 0;
+    a.cache_slot[i] = i; a.cache_slot_parent[i] = i;
     src_of[i] = i / a.K; cand_src_len[i] = 1;
   }
   if (tid == 0) {
@@ -1393,7 +1401,10 @@ __global__ void k_bsp_admit(BeamPoolArgs a, int* new_slot, int* cand_src_len, in
     a.src_state[s] = BP_RUNNING;
     a.bat_live[cur_slot] += 1;
     for (int q = 0; q < 8; ++q) a.src_acc[s * 8 + q] = 0;
-    for (int k = 0; k < a.K; ++k) { cand_src_len[s * a.K + k] = io.len_all[row]; a.cand_batch[s * a.K + k] = cur_slot; }
+    for (int k = 0; k < a.K; ++k) {
+      cand_src_len[s * a.K + k] = io.len_all[row]; a.cand_batch[s * a.K + k] = cur_slot;
+      a.cache_slot[s * a.K + k] = s * a.K + k; a.cache_slot_parent[s * a.K + k] = s * a.K + k;      // a new source: its K slots are all free
+    }
     ++s;
   }
   // the host only admits as many sources as it knows to be free, so got == R
@@ -1579,6 +1590,29 @@ __global__ __launch_bounds__(256) void k_bsp_select(BeamPoolArgs a) {
     else if (s_eos == K) st = BP_DONE;
     a.src_state[s] = st;
     if (enough) atomicMax(&a.bat_longest_cur[b], s_maxreal);
+    if (enough) {
+      // Cache slots of the K new candidates (k_tree_cache): a parent's slot goes to ONE of its children — a running one if there
+      // is one — which then only appends its accepted rows; every further child copies the parent's rows into the slot of a
+      // candidate without children (nobody reads that slot again).  K children, K slots: it always works out.  The candidates
+      // themselves stay in the order the selection gave them; only the attention's cache pointer goes through the map.
+      int old_slot[NUC_MAX_KEEP], par[NUC_MAX_KEEP], new_slot[NUC_MAX_KEEP];
+      for (int q = 0; q < K; ++q) { old_slot[q] = a.cache_slot[c0 + q]; new_slot[q] = -1; }
+      for (int r = 0; r < K; ++r) par[r] = (s_win[r] / K) / dl1;
+      unsigned taken = 0;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int r = 0; r < K; ++r) {
+          if (new_slot[r] >= 0 || (a.fin_next[c0 + r] ? 1 : 0) != pass) continue;
+          if (!((taken >> par[r]) & 1u)) { new_slot[r] = old_slot[par[r]]; taken |= 1u << par[r]; }
+        }
+      int q = 0;
+      for (int r = 0; r < K; ++r) {
+        if (new_slot[r] >= 0) continue;
+        while ((taken >> q) & 1u) ++q;
+        new_slot[r] = old_slot[q];
+        taken |= 1u << q;
+      }
+      for (int r = 0; r < K; ++r) { a.cache_slot_parent[c0 + r] = old_slot[par[r]]; a.cache_slot[c0 + r] = new_slot[r]; }
+    }
   }
 }
 
