@@ -1033,25 +1033,34 @@ struct BeamListArgs {
 // One workgroup: compact list of the running candidates (candidate order), the DecState the step kernels size their
 // work from, the iteration's counters, and the reset of the selection summary.
 __global__ __launch_bounds__(256) void k_bs_list(BeamListArgs a) {
-  __shared__ int s_scan[256];
+  __shared__ int s_cnt[4];
   __shared__ int s_lines, s_run, s_maxg, s_prefix;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t == 0) { s_lines = 0; s_run = 0; s_maxg = 0; s_prefix = 0; }
   __syncthreads();
+  auto wsum = [](int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+  auto wmax = [](int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64)); return v; };
   int before = 0;
   for (int base = 0; base < a.n_cand; base += 256) {
     const int c = base + t;
-    const int act = (c < a.n_cand && a.active[c]) ? 1 : 0;
-    const int incl = block_scan_incl256(act, s_scan);
-    if (c < a.n_cand) {
-      const int pc = a.per_cand[c];
-      a.slot_of[c] = act ? before + incl - 1 : -1;
-      a.prev_len[c] = a.len[c];
-      if (act) { a.act_idx[before + incl - 1] = c; atomicAdd(&s_run, pc); atomicAdd(&s_prefix, a.len[c] - 1); }
-      atomicAdd(&s_lines, pc);
-      atomicMax(&s_maxg, pc);
+    const bool in = c < a.n_cand;
+    const int act = (in && a.active[c]) ? 1 : 0;
+    const int pc = in ? a.per_cand[c] : 0, ln = in ? a.len[c] : 1;
+    // ordered compaction by ballots: running candidates of the earlier waves + running lanes below this one
+    const unsigned long long mask = __ballot(act);
+    if (lane == 0) s_cnt[wave] = __popcll(mask);
+    __syncthreads();
+    int below = 0, total = 0;
+    for (int w = 0; w < 4; ++w) { below += (w < wave) ? s_cnt[w] : 0; total += s_cnt[w]; }
+    const int pos = before + below + __popcll(mask & ((1ull << lane) - 1ull));
+    if (in) {
+      a.slot_of[c] = act ? pos : -1;
+      a.prev_len[c] = ln;
+      if (act) a.act_idx[pos] = c;
     }
-    before += s_scan[255];
+    const int lines = wsum(pc), run = wsum(act ? pc : 0), prefix = wsum(act ? ln - 1 : 0), maxg = wmax(pc);
+    if (lane == 0) { atomicAdd(&s_lines, lines); atomicAdd(&s_run, run); atomicAdd(&s_prefix, prefix); atomicMax(&s_maxg, maxg); }
+    before += total;
     __syncthreads();
   }
   if (t == 0) {
